@@ -1,0 +1,129 @@
+/*
+ * tamcmc_hip.h -- C ABI of the MI355X (gfx950) hot path of TAMCMC:
+ *   per-chain Lorentzian-sum model over the power-spectrum bins
+ *   -> chi^2(2 d.o.f.) log-likelihood reduction
+ *   -> finite-difference gradient for the Langevin proposal.
+ *
+ * Plain C: opaque context, plain pointers and sizes, int status codes
+ * (never exit()).  All pointers are HOST pointers unless a name ends in _dev.
+ * One context per host thread / GPU; a context is not thread-safe.
+ *
+ * The reference (OthmanB/TAMCMC-C, paths relative to its root) has no FFI:
+ * its boundary is the in-process call
+ *     Model_def::generate_model(Data*, m, Tcoefs)      tamcmc/sources/model_def.cpp:466-482
+ * made once per chain per iteration from
+ *     MALA::update_position_MH                         tamcmc/sources/MALA.cpp:486-488
+ * inside `#pragma omp parallel for` over chains        tamcmc/sources/MALA.cpp:648-668.
+ * Each entry point below names the reference interface it replaces.
+ * INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef TAMCMC_HIP_H
+#define TAMCMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- status codes ---------------- */
+#define TAMCMC_OK 0
+#define TAMCMC_ERR_HIP (-1)          /* a HIP runtime call failed (tamcmc_hip_last_error has the text) */
+#define TAMCMC_ERR_EMPTY_WINDOW (-2) /* set_imin_imax: imax-imin<=0 (reference exits, build_lorentzian.cpp:650-665) */
+#define TAMCMC_ERR_NAN_WINDOW (-3)   /* NaN width/splitting: no window regime applies (build_lorentzian.cpp:597-634) */
+#define TAMCMC_ERR_BAD_MODEL (-4)    /* model id without a device table builder (model_def.cpp:352-385) */
+#define TAMCMC_ERR_BAD_ARG (-5)
+#define TAMCMC_ERR_NO_SPECTRUM (-6)
+#define TAMCMC_ERR_NO_DEVICE (-7)    /* no HIP device: the product path has NO CPU fallback */
+
+/* ---------------- model ids (Config/default/models_ctrl.list) ---------------- */
+#define TAMCMC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC 3 /* model_MS_Global_a1etaa3_HarveyLike_Classic, models.cpp:1943 */
+#define TAMCMC_MODEL_MS_LOCAL_BASIC 11           /* model_MS_local_basic, models.cpp:3012 */
+#define TAMCMC_MODEL_MS_GLOBAL_AJ 23             /* model_MS_Global_aj_HarveyLike, models.cpp:1195 */
+
+/* ---------------- arithmetic modes ---------------- */
+/* STRICT: per-bin operation order of the reference (IEEE divides, no FMA contraction): the model row is
+ *         bit-identical to the CPU restatement when the Harvey pow() terms are inactive.
+ * FAST  : same function, re-associated (common-denominator multiplet sum, reciprocal+Newton, exp/log Harvey);
+ *         stated tolerance: |dM|/M <= 1e-12 per bin, |dlogL|/|logL| <= 1e-11. */
+#define TAMCMC_PRECISION_STRICT 0
+#define TAMCMC_PRECISION_FAST 1
+
+#define TAMCMC_OPT_PRECISION 1   /* value: TAMCMC_PRECISION_* (default STRICT) */
+#define TAMCMC_OPT_TIMING 2      /* value: 0/1 -- bracket the likelihood kernel with HIP events on the context stream */
+#define TAMCMC_OPT_BINS_PER_THREAD 3 /* value: 1,2,4 -- tile = 256*value bins per workgroup */
+
+/* One (n,l) multiplet: <=7 Lorentzian m-components on its truncation window.
+ * This is the flat "mode table" row every Lorentzian model of the dispatch table reduces to
+ * (build_lorentzian.cpp:131-161, :208-246).  152 bytes, no padding. */
+typedef struct tamcmc_multiplet {
+    int32_t l;      /* degree 0..3 -> 2l+1 components */
+    int32_t i0;     /* first bin of the window (set_imin_imax, build_lorentzian.cpp:645-649) */
+    int32_t i1;     /* one past the last bin */
+    int32_t flags;  /* reserved, 0 */
+    double fc;      /* central frequency nu_c (asymmetry reference, build_lorentzian.cpp:240) */
+    double gamma;   /* width */
+    double asym;    /* asymmetry coefficient (0 = symmetric Lorentzian) */
+    double nu[7];   /* nu_nlm for m=-l..l */
+    double hv[7];   /* H_l * V_m */
+} tamcmc_multiplet;
+
+typedef struct tamcmc_hip_ctx tamcmc_hip_ctx;
+
+/* ---------------- context ---------------- */
+int tamcmc_hip_create(tamcmc_hip_ctx **ctx, int device);
+void tamcmc_hip_destroy(tamcmc_hip_ctx *ctx);
+const char *tamcmc_hip_last_error(const tamcmc_hip_ctx *ctx);
+int tamcmc_hip_set_option(tamcmc_hip_ctx *ctx, int option, int64_t value);
+const char *tamcmc_hip_version(void);
+
+/* Replaces the shared read-only `Data{x,y,Nx}` (tamcmc/headers/data.h:23-34) every chain reads:
+ * uploads the spectrum once; it stays resident in HBM. x must be a regular grid (build_lorentzian.cpp:645). */
+int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *ctx, const double *x, const double *y, int64_t Nx);
+
+/* Replaces, for B parameter vectors at once, the per-bin work of
+ *   call_model  (model_def.cpp:220-388 -> optimum_lorentzian_calc_* + harvey_like, noise_models.cpp:15-39)
+ *   call_likelihood (model_def.cpp:390-419 -> likelihood_chi22p, likelihoods.cpp:17-28).
+ * mults[offsets[b] .. offsets[b+1]) are evaluation b's multiplets in the reference's accumulation order;
+ * noise + b*noise_stride = |noise params| [H0,tau0,p0,...,N0] with nharvey[b] Harvey terms, white noise at
+ * index 3*nharvey[b] ... the LAST of the b-th row's nnoise[b] entries;
+ * Tcoefs[b] = temperature (NULL -> 1); p = likelihood_params truncated to long.
+ * Out: logL[b] = -p * sum_i(y_i/M_i + ln M_i) / Tcoefs[b]; model (may be NULL) = B x Nx rows.
+ * A non-finite model gives a NaN/inf logL that the caller rejects (MALA.cpp:490,522-524). */
+int tamcmc_hip_loglike_batch(tamcmc_hip_ctx *ctx, int B, const tamcmc_multiplet *mults, const int32_t *offsets,
+                             const double *noise, int noise_stride, const int32_t *nharvey, const int32_t *nnoise,
+                             const double *Tcoefs, double p, double *logL, double *model);
+
+/* Table builders: the host-side scalar part of the model functions
+ *   VectorXd model_X(params, params_length, x, outparams)   tamcmc/headers/models.h:21-57
+ * (parameter unpack, amplitude_ratio, lin_interpol, eta0, set_imin_imax) for ids 3, 11, 23.
+ * Writes at most max_mults rows; *n_mults = rows needed.  noise_abs receives |noise params| (plength[8] values). */
+int tamcmc_build_mode_table(int model_id, const double *params, const int32_t *plength, const double *x, int64_t Nx,
+                            tamcmc_multiplet *mults, int max_mults, int *n_mults, double *noise_abs,
+                            int *nharvey, int *nnoise);
+
+/* model id + params level: table build on the host for each of the B vectors, then one batched device call.
+ * This is the batched body of Model_def::generate_model without the prior (model_def.cpp:473-474).
+ * status (may be NULL) receives the per-vector table status; vectors with a failed table get logL = NaN. */
+int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *ctx, int model_id, int B, const double *params, int64_t Nparams,
+                                    const int32_t *plength, const double *Tcoefs, double p, double *logL,
+                                    double *model, int32_t *status);
+
+/* Forward-difference gradient of the tempered logL (the drift MALA::D_MALA leaves as a stub, MALA.cpp:321-328):
+ * for each of the C chains, Nvars+1 evaluations in ONE batched launch.
+ * params: C x Nparams; index_to_relax: Nvars parameter indices (model_def.cpp:76-90); hstep: Nvars steps.
+ * Out: logL0[C], grad[C x Nvars] = (logL(theta + h e_k) - logL(theta)) / h_applied. */
+int tamcmc_hip_fd_gradient(tamcmc_hip_ctx *ctx, int model_id, int C, const double *params, int64_t Nparams,
+                           const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep,
+                           const double *Tcoefs, double p, double *logL0, double *grad);
+
+/* Timing of the likelihood kernel measured with HIP events on the context's own stream
+ * (enabled by TAMCMC_OPT_TIMING): totals since the last reset. */
+int tamcmc_hip_get_kernel_stats(tamcmc_hip_ctx *ctx, double *kernel_ms_total, int64_t *launches,
+                                int64_t *evaluations);
+int tamcmc_hip_reset_kernel_stats(tamcmc_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMCMC_HIP_H */

@@ -1,0 +1,128 @@
+/*
+ * tamcmc_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A from-scratch plain-C restatement of the TAMCMC-C hot path
+ *   Model_def::generate_model = prior -> call_model -> call_likelihood
+ * used ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * as the checker / CPU baseline.  The product path (tamcmc-c_amd/) never
+ * includes, links or calls anything declared here.
+ *
+ * Pinning status: the reference (/root/reference) cannot be compiled in the
+ * authoring container (every hot-path TU needs Eigen3; build_lorentzian.h pulls
+ * GSL and Boost) and its tests hold no stored numbers.  The oracle is pinned by
+ *   (i)  tests/golden/acoefs_py.json : Pslm / nu_nlm values produced by the
+ *        reference's own importable python helper test/lorentzian_test/acoefs.py
+ *        (generator: tests/golden/make_acoefs_golden.py),
+ *   (ii) analytic known-answer tests (tests/test_oracle_kat.py),
+ *   (iii) the reference's own acceptance bound ||new-ref||_2 <= 1e-8
+ *        (test/lorentzian_test/unit_tests/test_build_l_mode.cpp:104,134).
+ * Everything not covered by (i)-(iii) is "parity unpinned by the reference".
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose meaning it restates.
+ */
+#ifndef TAMCMC_ORACLE_H
+#define TAMCMC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define ORC_OK 0
+#define ORC_ERR_EMPTY_WINDOW (-2)  /* build_lorentzian.cpp:650-665 (reference exits) */
+#define ORC_ERR_NAN_WINDOW (-3)    /* SURVEY App. D caveat: NaN gamma/f_s leaves pvals unset */
+#define ORC_ERR_BAD_MODEL (-4)     /* model_def.cpp:352-385 (reference exits) */
+#define ORC_ERR_BAD_ARG (-5)
+
+/* model ids = Config/default/models_ctrl.list */
+#define ORC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC 3
+#define ORC_MODEL_MS_LOCAL_BASIC 11
+#define ORC_MODEL_MS_GLOBAL_AJ 23
+
+/* ---- scalar helpers ---- */
+long double orc_Pslm(int s, int l, int m);               /* acoefs.cpp:51-110 */
+long double orc_Hslm_Ritzoller1991(int s, int l, int m); /* acoefs.cpp:19-49 */
+double orc_Qlm(int l, int m);                            /* build_lorentzian.cpp:583-592 */
+void orc_amplitude_ratio(int l, double beta_deg, double *V /*2l+1*/); /* function_rot.cpp:15-41 */
+double orc_lin_interpol(const double *x, const double *y, long n, double x_int); /* interpol.cpp:13-43 */
+void orc_linfit(const double *x, const double *y, long n, double out[2]);        /* linfit.cpp:17-35 */
+double orc_eta0_from_dnu(double dnu);                    /* models.cpp:6073-6084 */
+double orc_eta0_fct(const double *fl0, long n);          /* models.cpp:6065-6071 */
+int orc_set_imin_imax(const double *x, long Nx, int l, double fc_l, double gamma_l, double f_s,
+                      double c, double step, int ivals[2]); /* build_lorentzian.cpp:595-676 */
+
+/* ---- multiplet builders on a window x_l[0..N) -> result[0..N) ---- */
+void orc_build_l_mode_a1etaa3(const double *x_l, long N, double H_l, double fc_l, double f_s, double eta0,
+                              double a3, double asym, double gamma_l, int l, const double *V,
+                              double *result); /* build_lorentzian.cpp:131-161 */
+void orc_build_l_mode_aj(const double *x_l, long N, double H_l, double fc_l, double a1, double a2, double a3,
+                         double a4, double a5, double a6, double eta0, double asym, double gamma_l, int l,
+                         const double *V, double *result); /* build_lorentzian.cpp:208-246 */
+/* split-frequency helpers exposed for the golden-vector tests */
+double orc_nu_nlm_aj(double fc_l, double a1, double a2, double a3, double a4, double a5, double a6,
+                     double eta0, int l, int m); /* build_lorentzian.cpp:226-229 */
+double orc_nu_nlm_a1etaa3(double fc_l, double f_s, double eta0, double a3, int l, int m); /* :145 */
+
+/* windowed accumulate: model[i0..i1) += multiplet */
+int orc_optimum_lorentzian_calc_a1etaa3(const double *x, double *model, long Nx, double H_l, double fc_l,
+                                        double f_s, double eta0, double a3, double asym, double gamma_l,
+                                        int l, const double *V, double step, double c); /* :441-458 */
+int orc_optimum_lorentzian_calc_aj(const double *x, double *model, long Nx, double H_l, double fc_l, double a1,
+                                   double a2, double a3, double a4, double a5, double a6, double eta0,
+                                   double asym, double gamma_l, int l, const double *V, double step,
+                                   double c); /* :502-522 + caller add models.cpp:1297-1298 */
+
+/* ---- background and likelihood ---- */
+void orc_harvey_like(const double *noise_params_abs, long Nnoise, const double *x, double *model, long Nx,
+                     int Nharvey); /* noise_models.cpp:15-39 (in place: model += background) */
+long double orc_likelihood_chi22p(const double *y, const double *model, long Nx, long p); /* likelihoods.cpp:17-28 */
+/* same quantity with 80-bit accumulators: the "truth" used to size tolerances */
+long double orc_likelihood_chi22p_ld(const double *y, const double *model, long Nx, long p);
+
+/* ---- model functions: params/plength -> model[Nx] (models.h:21-57) ---- */
+int orc_model_MS_Global_aj_HarveyLike(const double *params, const int *plength, const double *x, long Nx,
+                                      double *model); /* models.cpp:1195-1408 */
+int orc_model_MS_Global_a1etaa3_HarveyLike_Classic(const double *params, const int *plength, const double *x,
+                                                   long Nx, double *model); /* models.cpp:1943-2121 */
+int orc_model_MS_local_basic(const double *params, const int *plength, const double *x, long Nx,
+                             double *model); /* models.cpp:3012-3195 */
+int orc_call_model(int model_id, const double *params, const int *plength, const double *x, long Nx,
+                   double *model); /* model_def.cpp:220-388 */
+
+/* call_likelihood (model_def.cpp:390-419): chi22p / Tcoef */
+double orc_call_likelihood(const double *y, const double *model, long Nx, double likelihood_params, double Tcoef);
+
+/* batched driver used for parity and as CPU baseline: for each b, model -> tempered logL.
+ * OpenMP over b like MALA.cpp:648.  model_out may be NULL.  Returns first nonzero status. */
+int orc_loglike_batch(int model_id, int B, const double *params /*B x Nparams*/, long Nparams,
+                      const int *plength, const double *x, const double *y, long Nx, double likelihood_params,
+                      const double *Tcoefs /*B*/, double *logL /*B*/, double *model_out /*B x Nx or NULL*/,
+                      int *status /*B or NULL*/);
+
+/* forward-difference gradient of the tempered logL wrt the relaxed parameters
+ * (oracle of the path the reference leaves as a stub, MALA.cpp:321-337) */
+int orc_fd_gradient(int model_id, const double *params, long Nparams, const int *plength,
+                    const int *index_to_relax, int Nvars, const double *hstep /*Nvars*/, const double *x,
+                    const double *y, long Nx, double likelihood_params, double Tcoef, double *logL0,
+                    double *grad /*Nvars*/);
+
+/* ---- priors (stats_dictionary.cpp; priors_calc.cpp:725-870) ---- */
+long double orc_logP_uniform(double b_min, double b_max, double x);                /* stats_dictionary.cpp:38-52 */
+long double orc_logP_gaussian(double mean, double sigma, double x);                /* :98-105 */
+long double orc_logP_jeffrey(double hmin, double hmax, double h);                  /* :127-143 */
+long double orc_logP_uniform_abs(double b_min, double b_max, double x);            /* :56-70 */
+long double orc_logP_jeffrey_abs(double hmin, double hmax, double h);              /* :149-165 */
+long double orc_logP_gaussian_uniform(double b_min, double b_max, double sigma, double x);          /* GU  */
+long double orc_logP_uniform_gaussian(double b_min, double b_max, double sigma, double x);          /* UG  */
+long double orc_logP_gug(double b_min, double b_max, double sigma1, double sigma2, double x);       /* GUG */
+/* apply_generic_priors over parameters [i0, i0+n): priors table is 4 x Nparams row-major */
+long double orc_apply_generic_priors(const double *params, long i0, long n, const double *priors, long Nparams,
+                                     const int *priors_names_switch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

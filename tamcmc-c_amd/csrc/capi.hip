@@ -1,0 +1,365 @@
+// capi.hip -- the C-ABI layer of include/tamcmc_hip.h: context, resident spectrum, staging buffers,
+// batched likelihood launches.  One context owns one HIP stream on one device; host<->device staging goes
+// through pinned buffers so that the small per-call tables travel with hipMemcpyAsync on that stream.
+// There is NO CPU fallback: without a HIP device every entry point fails with TAMCMC_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tamcmc_hip.h"
+#include "kernels.h"
+#include "mode_tables.h"
+
+namespace {
+
+template <typename T>
+struct DevBuf {  // grow-only device buffer
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 2 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinBuf {  // grow-only pinned host buffer
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 2 + 64;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct tamcmc_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // options
+    int precision = TAMCMC_PRECISION_STRICT;
+    int timing = 0;
+    int K = 2;
+    // resident spectrum
+    int64_t Nx = 0;
+    std::vector<double> hx;  // host copy of x (table builders need x[0], x[Nx-1], step)
+    DevBuf<double> dx, dy, dlogx;
+    // staging
+    DevBuf<tamcmc_multiplet> d_mults;
+    DevBuf<int32_t> d_off, d_nh, d_nn;
+    DevBuf<double> d_noise, d_part, d_S, d_model;
+    PinBuf<tamcmc_multiplet> h_mults;
+    PinBuf<int32_t> h_off, h_nh, h_nn;
+    PinBuf<double> h_noise, h_S;
+    // stats
+    double kernel_ms = 0;
+    int64_t launches = 0, evals = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return TAMCMC_ERR_HIP;                                                            \
+        }                                                                                     \
+    } while (0)
+
+extern "C" {
+
+const char *tamcmc_hip_version(void) { return "tamcmc-c_amd 0.1 (gfx950)"; }
+
+int tamcmc_hip_create(tamcmc_hip_ctx **out, int device) {
+    if (!out) return TAMCMC_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TAMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return TAMCMC_ERR_BAD_ARG;
+    tamcmc_hip_ctx *c = new tamcmc_hip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return TAMCMC_ERR_HIP;
+    }
+    *out = c;
+    return TAMCMC_OK;
+}
+
+void tamcmc_hip_destroy(tamcmc_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->dx.release(); c->dy.release(); c->dlogx.release();
+    c->d_mults.release(); c->d_off.release(); c->d_nh.release(); c->d_nn.release();
+    c->d_noise.release(); c->d_part.release(); c->d_S.release(); c->d_model.release();
+    c->h_mults.release(); c->h_off.release(); c->h_nh.release(); c->h_nn.release();
+    c->h_noise.release(); c->h_S.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *tamcmc_hip_last_error(const tamcmc_hip_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    switch (option) {
+    case TAMCMC_OPT_PRECISION:
+        if (value != TAMCMC_PRECISION_STRICT && value != TAMCMC_PRECISION_FAST) return TAMCMC_ERR_BAD_ARG;
+        c->precision = (int)value;
+        return TAMCMC_OK;
+    case TAMCMC_OPT_TIMING: c->timing = value ? 1 : 0; return TAMCMC_OK;
+    case TAMCMC_OPT_BINS_PER_THREAD:
+        if (value != 1 && value != 2 && value != 4) return TAMCMC_ERR_BAD_ARG;
+        c->K = (int)value;
+        return TAMCMC_OK;
+    default: return TAMCMC_ERR_BAD_ARG;
+    }
+}
+
+int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *c, const double *x, const double *y, int64_t Nx) {
+    if (!c || !x || !y || Nx < 2 || Nx > 0x7fffffff) return TAMCMC_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->hx.assign(x, x + Nx);
+    std::vector<double> lx((size_t)Nx);
+    for (int64_t i = 0; i < Nx; i++) lx[(size_t)i] = std::log(x[i]);  // FAST Harvey terms: (a x)^p = exp(p (ln a + ln x))
+    HIPCHK(c, c->dx.reserve((size_t)Nx));
+    HIPCHK(c, c->dy.reserve((size_t)Nx));
+    HIPCHK(c, c->dlogx.reserve((size_t)Nx));
+    HIPCHK(c, hipMemcpyAsync(c->dx.p, x, (size_t)Nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dy.p, y, (size_t)Nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dlogx.p, lx.data(), (size_t)Nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->Nx = Nx;
+    return TAMCMC_OK;
+}
+
+// Launch on tables already staged in the pinned buffers h_mults/h_off/h_nh/h_nn/h_noise.
+static int run_staged(tamcmc_hip_ctx *c, int B, size_t total_mults, int noise_stride, const double *Tcoefs, double p,
+                      double *logL, double *model) {
+    const int Nx = (int)c->Nx;
+    const int tb = tamcmc::tile_bins(c->K);
+    const int ntiles = (Nx + tb - 1) / tb;
+    HIPCHK(c, c->d_mults.reserve(total_mults + 1));
+    HIPCHK(c, c->d_off.reserve((size_t)B + 1));
+    HIPCHK(c, c->d_nh.reserve((size_t)B));
+    HIPCHK(c, c->d_nn.reserve((size_t)B));
+    HIPCHK(c, c->d_noise.reserve((size_t)B * noise_stride));
+    HIPCHK(c, c->d_part.reserve((size_t)B * ntiles * 2));
+    HIPCHK(c, c->d_S.reserve((size_t)B));
+    HIPCHK(c, c->h_S.reserve((size_t)B));
+    if (model) HIPCHK(c, c->d_model.reserve((size_t)B * Nx));
+    hipStream_t st = c->stream;
+    if (total_mults)
+        HIPCHK(c, hipMemcpyAsync(c->d_mults.p, c->h_mults.p, total_mults * sizeof(tamcmc_multiplet), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_off.p, c->h_off.p, ((size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_nh.p, c->h_nh.p, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_nn.p, c->h_nn.p, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_noise.p, c->h_noise.p, (size_t)B * noise_stride * sizeof(double), hipMemcpyHostToDevice, st));
+
+    tamcmc::LoglikeArgs a;
+    a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.B = B; a.ntiles = ntiles;
+    a.mults = c->d_mults.p; a.offsets = c->d_off.p; a.noise = c->d_noise.p; a.noise_stride = noise_stride;
+    a.nharvey = c->d_nh.p; a.nnoise = c->d_nn.p; a.partials = c->d_part.p; a.model = model ? c->d_model.p : nullptr;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+    HIPCHK(c, tamcmc::launch_loglike(a, c->precision == TAMCMC_PRECISION_FAST, c->K, model != nullptr, st));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, tamcmc::launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_S.p, c->d_S.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (model)
+        HIPCHK(c, hipMemcpyAsync(model, c->d_model.p, (size_t)B * Nx * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (c->timing) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->kernel_ms += ms;
+        c->launches += 1;
+        c->evals += B;
+    }
+    // call_likelihood (model_def.cpp:399-401): f = -p*(sum1+sum2) in long double, then / Tcoefs[m]
+    const long pl = (long)p;
+    for (int b = 0; b < B; b++) {
+        long double f = c->h_S.p[b];
+        f = -pl * f;
+        logL[b] = (double)(f / (Tcoefs ? Tcoefs[b] : 1.0));
+    }
+    return TAMCMC_OK;
+}
+
+int tamcmc_hip_loglike_batch(tamcmc_hip_ctx *c, int B, const tamcmc_multiplet *mults, const int32_t *offsets,
+                             const double *noise, int noise_stride, const int32_t *nharvey, const int32_t *nnoise,
+                             const double *Tcoefs, double p, double *logL, double *model) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    if (c->Nx <= 0) return TAMCMC_ERR_NO_SPECTRUM;
+    if (B < 0 || !offsets || !noise || !nharvey || !nnoise || !logL || noise_stride < 1) return TAMCMC_ERR_BAD_ARG;
+    if (B == 0) return TAMCMC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // validate what the kernel's indexing assumes before anything reaches the GPU
+    if (offsets[0] != 0) return TAMCMC_ERR_BAD_ARG;
+    for (int b = 0; b < B; b++) {
+        if (offsets[b + 1] < offsets[b]) return TAMCMC_ERR_BAD_ARG;
+        if (nnoise[b] < 1 || nnoise[b] > noise_stride) return TAMCMC_ERR_BAD_ARG;
+        if (nharvey[b] < 0 || nharvey[b] > TAMCMC_MAX_HARVEY || 3 * nharvey[b] + 1 > nnoise[b]) return TAMCMC_ERR_BAD_ARG;
+    }
+    const size_t total = (size_t)offsets[B];
+    if (total && !mults) return TAMCMC_ERR_BAD_ARG;
+    for (size_t i = 0; i < total; i++) {
+        const tamcmc_multiplet &m = mults[i];
+        if (m.l < 0 || m.l > 3 || m.i0 < 0 || m.i1 > c->Nx || m.i1 <= m.i0) return TAMCMC_ERR_BAD_ARG;
+    }
+    HIPCHK(c, c->h_mults.reserve(total + 1));
+    HIPCHK(c, c->h_off.reserve((size_t)B + 1));
+    HIPCHK(c, c->h_nh.reserve((size_t)B));
+    HIPCHK(c, c->h_nn.reserve((size_t)B));
+    HIPCHK(c, c->h_noise.reserve((size_t)B * noise_stride));
+    if (total) std::memcpy(c->h_mults.p, mults, total * sizeof(tamcmc_multiplet));
+    std::memcpy(c->h_off.p, offsets, ((size_t)B + 1) * sizeof(int32_t));
+    std::memcpy(c->h_nh.p, nharvey, (size_t)B * sizeof(int32_t));
+    std::memcpy(c->h_nn.p, nnoise, (size_t)B * sizeof(int32_t));
+    std::memcpy(c->h_noise.p, noise, (size_t)B * noise_stride * sizeof(double));
+    return run_staged(c, B, total, noise_stride, Tcoefs, p, logL, model);
+}
+
+// Build the B tables straight into the pinned staging buffers.  Vectors whose table fails keep an empty
+// table; their status is reported and their logL is forced to NaN afterwards.
+static int stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *params, int64_t Nparams,
+                        const int32_t *plength, int32_t *status, size_t *total_out, int *stride_out, int *first_err) {
+    const int per = tamcmc::count_multiplets(model_id, plength);
+    if (per < 0) return TAMCMC_ERR_BAD_MODEL;
+    const int stride = plength[8] > 0 ? plength[8] : 1;
+    if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
+    HIPCHK(c, c->h_mults.reserve((size_t)B * per + 1));
+    HIPCHK(c, c->h_off.reserve((size_t)B + 1));
+    HIPCHK(c, c->h_nh.reserve((size_t)B));
+    HIPCHK(c, c->h_nn.reserve((size_t)B));
+    HIPCHK(c, c->h_noise.reserve((size_t)B * stride));
+    size_t total = 0;
+    *first_err = TAMCMC_OK;
+    c->h_off.p[0] = 0;
+    for (int b = 0; b < B; b++) {
+        int n = 0, nh = 0, nn = 0;
+        int st = tamcmc::build_mode_table(model_id, params + (size_t)b * Nparams, plength, c->hx.data(), c->Nx,
+                                          c->h_mults.p + total, per, &n, c->h_noise.p + (size_t)b * stride, &nh, &nn);
+        if (st == TAMCMC_OK && n > per) st = TAMCMC_ERR_BAD_ARG;
+        if (status) status[b] = st;
+        if (st != TAMCMC_OK) {
+            if (*first_err == TAMCMC_OK) *first_err = st;
+            n = 0; nh = 0; nn = 1;
+            c->h_noise.p[(size_t)b * stride] = 1.0;  // harmless placeholder row; logL[b] is overwritten with NaN
+        }
+        total += (size_t)n;
+        c->h_off.p[b + 1] = (int32_t)total;
+        c->h_nh.p[b] = nh;
+        c->h_nn.p[b] = nn;
+    }
+    *total_out = total;
+    *stride_out = stride;
+    return TAMCMC_OK;
+}
+
+int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, const double *params, int64_t Nparams,
+                                    const int32_t *plength, const double *Tcoefs, double p, double *logL,
+                                    double *model, int32_t *status) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    if (c->Nx <= 0) return TAMCMC_ERR_NO_SPECTRUM;
+    if (B < 0 || !params || !plength || !logL || Nparams < 1) return TAMCMC_ERR_BAD_ARG;
+    if (B == 0) return TAMCMC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t total = 0;
+    int stride = 1, first_err = TAMCMC_OK;
+    std::vector<int32_t> st_local;
+    if (!status) { st_local.resize((size_t)B); status = st_local.data(); }
+    int rc = stage_params(c, model_id, B, params, Nparams, plength, status, &total, &stride, &first_err);
+    if (rc) return rc;
+    rc = run_staged(c, B, total, stride, Tcoefs, p, logL, model);
+    if (rc) return rc;
+    for (int b = 0; b < B; b++)
+        if (status[b] != TAMCMC_OK) logL[b] = NAN;
+    return first_err;
+}
+
+int tamcmc_hip_fd_gradient(tamcmc_hip_ctx *c, int model_id, int C, const double *params, int64_t Nparams,
+                           const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep,
+                           const double *Tcoefs, double p, double *logL0, double *grad) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    if (C < 0 || Nvars < 0 || !params || !plength || !index_to_relax || !hstep || !logL0 || !grad) return TAMCMC_ERR_BAD_ARG;
+    if (C == 0) return TAMCMC_OK;
+    for (int k = 0; k < Nvars; k++)
+        if (index_to_relax[k] < 0 || index_to_relax[k] >= Nparams) return TAMCMC_ERR_BAD_ARG;
+    const int E = Nvars + 1;
+    std::vector<double> P((size_t)C * E * Nparams), T((size_t)C * E), L((size_t)C * E), happ((size_t)C * Nvars);
+    for (int ch = 0; ch < C; ch++) {
+        const double *src = params + (size_t)ch * Nparams;
+        for (int e = 0; e < E; e++) {
+            double *dst = P.data() + ((size_t)ch * E + e) * Nparams;
+            std::memcpy(dst, src, (size_t)Nparams * sizeof(double));
+            T[(size_t)ch * E + e] = Tcoefs ? Tcoefs[ch] : 1.0;
+            if (e > 0) {
+                const int i = index_to_relax[e - 1];
+                volatile double xp = src[i] + hstep[e - 1];
+                dst[i] = xp;
+                happ[(size_t)ch * Nvars + e - 1] = xp - src[i];  // the step actually applied
+            }
+        }
+    }
+    std::vector<int32_t> status((size_t)C * E);
+    int rc = tamcmc_hip_loglike_params_batch(c, model_id, C * E, P.data(), Nparams, plength, T.data(), p, L.data(),
+                                             nullptr, status.data());
+    if (rc == TAMCMC_ERR_HIP || rc == TAMCMC_ERR_BAD_ARG || rc == TAMCMC_ERR_BAD_MODEL || rc == TAMCMC_ERR_NO_SPECTRUM)
+        return rc;
+    for (int ch = 0; ch < C; ch++) {
+        logL0[ch] = L[(size_t)ch * E];
+        for (int k = 0; k < Nvars; k++)
+            grad[(size_t)ch * Nvars + k] = (L[(size_t)ch * E + k + 1] - L[(size_t)ch * E]) / happ[(size_t)ch * Nvars + k];
+    }
+    return rc;
+}
+
+int tamcmc_hip_get_kernel_stats(tamcmc_hip_ctx *c, double *kernel_ms_total, int64_t *launches, int64_t *evaluations) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    if (kernel_ms_total) *kernel_ms_total = c->kernel_ms;
+    if (launches) *launches = c->launches;
+    if (evaluations) *evaluations = c->evals;
+    return TAMCMC_OK;
+}
+
+int tamcmc_hip_reset_kernel_stats(tamcmc_hip_ctx *c) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    c->kernel_ms = 0;
+    c->launches = 0;
+    c->evals = 0;
+    return TAMCMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+// kernels.h -- launch interface between the C-ABI layer (capi.hip) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tamcmc_hip.h"
+
+#define TAMCMC_MAX_HARVEY 16
+
+namespace tamcmc {
+
+struct LoglikeArgs {
+    const double *x;      // [Nx] frequencies, resident
+    const double *y;      // [Nx] power, resident
+    const double *logx;   // [Nx] ln(x) (FAST Harvey terms), resident
+    int Nx;
+    int B;                // evaluations in this launch
+    int ntiles;           // filled by launch_loglike
+    const tamcmc_multiplet *mults;  // concatenated multiplet tables
+    const int32_t *offsets;         // [B+1]
+    const double *noise;            // [B x noise_stride] |noise params|
+    int noise_stride;
+    const int32_t *nharvey;         // [B]
+    const int32_t *nnoise;          // [B]
+    double *partials;               // [B x ntiles x 2]
+    double *model;                  // [B x Nx] or nullptr
+};
+
+int tile_bins(int K);
+hipError_t launch_loglike(LoglikeArgs a, bool fast, int K, bool write_model, hipStream_t st);
+hipError_t launch_finalize(const double *partials, int B, int ntiles, double *S, hipStream_t st);
+
+}  // namespace tamcmc

@@ -1,0 +1,309 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the TAMCMC hot path.
+//
+// k_loglike : fused  model row (sum of truncated Lorentzian multiplets + Harvey background)
+//             -> chi^2(2 d.o.f.) terms y/M + ln M -> per-workgroup partial sums
+//             (replaces build_l_mode_* build_lorentzian.cpp:131-161,208-246, the windowed adds of
+//              optimum_lorentzian_calc_* :441-458,502-522, harvey_like noise_models.cpp:15-39 and
+//              likelihood_chi22p likelihoods.cpp:17-28 of the reference, for a whole batch of chains)
+// k_finalize: deterministic second-level reduction of the partials, one workgroup per evaluation.
+//
+// Mapping: one workgroup = 256 threads = 4 wave64 = one tile of 256*K consecutive bins of ONE evaluation.
+// x/y are read coalesced (lane i -> bin base+i); the multiplets whose window intersects the tile are
+// compacted IN ORDER into LDS by wave 0 (ballot + popcount prefix) and then broadcast-read by every lane;
+// the log-likelihood terms are reduced with wave64 shuffles, then across the 4 waves through LDS.
+// No MFMA: the path is elementwise + reduction, bounded by fp64 VALU (divide) throughput, not by a contraction.
+// Block index -> (tile, evaluation) is XCD-aware: blocks b, b+8, b+16.. share an XCD (round-robin dispatch),
+// so all evaluations of one tile are placed on the same XCD and re-read x/y from that XCD's L2.
+//
+// Two arithmetic modes (see include/tamcmc_hip.h): STRICT keeps the reference's per-bin operation order
+// (this file is compiled with -ffp-contract=off; every fused multiply-add below is an explicit fma()).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace tamcmc {
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int CHUNK = 64;  // multiplets staged per pass: one wave compacts one chunk
+
+// LDS image of a multiplet, with the per-multiplet scalars hoisted out of the per-bin loop.
+struct LdsMult {
+    int l, i0, i1, pad;
+    double fc;    // nu_c
+    double g;     // STRICT: gamma^2          FAST: 2/gamma
+    double asym;  // asymmetry coefficient
+    double c2sq;  // (0.5*gamma*asym/fc)^2
+    double afc;   // FAST: asym/fc
+    double nu[7];
+    double hv[7];
+};
+
+__device__ __forceinline__ double rcp_nr(double d) {
+    // v_rcp_f64 seed + two Newton-Raphson steps (explicit fma): ~1 ulp reciprocal without the
+    // div_scale/div_fmas/div_fixup sequence of an IEEE divide.
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce(double (&v)[NV], double *s_red, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] = v[i] + __shfl_down(v[i], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) s_red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            double s = s_red[i];
+            for (int w = 1; w < WG / 64; w++) s = s + s_red[w * NV + i];
+            out[i] = s;
+        }
+    }
+}
+
+template <bool FAST, int K, bool WRITE_MODEL>
+__global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
+    __shared__ LdsMult s_m[CHUNK];
+    __shared__ int s_n;
+    __shared__ double s_red[2 * (WG / 64)];
+    __shared__ double s_lt[TAMCMC_MAX_HARVEY];  // FAST: ln(1e-3*tau_k)
+
+    // ---- XCD-aware block -> (tile, evaluation) ----
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int j = id >> 3;
+    const int b = j % a.B;
+    const int tile = (j / a.B) * 8 + xcd;
+    if (tile >= a.ntiles) return;  // whole workgroup leaves before any barrier
+
+    const int tid = threadIdx.x;
+    constexpr int TILE = WG * K;
+    const int t0 = tile * TILE;
+    const int t1 = min(t0 + TILE, a.Nx);
+
+    double xv[K], acc[K];
+    int bin[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        bin[k] = t0 + k * WG + tid;
+        const int bi = min(bin[k], a.Nx - 1);
+        xv[k] = a.x[bi];
+        acc[k] = 0.0;
+    }
+
+    const double *nz = a.noise + (size_t)b * a.noise_stride;
+    const int nh = a.nharvey[b];
+    const int nn = a.nnoise[b];
+    if (FAST) {
+        if (tid < nh) {
+            const double tau = nz[3 * tid + 1];
+            s_lt[tid] = log(1e-3 * tau);
+        }
+    }
+
+    const int mbeg = a.offsets[b], mend = a.offsets[b + 1];
+    for (int c0 = mbeg; c0 < mend; c0 += CHUNK) {
+        __syncthreads();  // previous chunk fully consumed
+        if (tid < 64) {
+            const int idx = c0 + tid;
+            bool ov = false;
+            int i0 = 0, i1 = 0;
+            if (idx < mend) {
+                i0 = a.mults[idx].i0;
+                i1 = a.mults[idx].i1;
+                ov = (i0 < t1) && (i1 > t0);
+            }
+            const unsigned long long mask = __ballot(ov);
+            if (ov) {
+                const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+                const tamcmc_multiplet &g = a.mults[idx];
+                LdsMult &d = s_m[pos];
+                d.l = g.l; d.i0 = i0; d.i1 = i1; d.pad = 0;
+                d.fc = g.fc; d.asym = g.asym;
+                const double c2 = 0.5 * g.gamma * g.asym / g.fc;
+                d.c2sq = c2 * c2;
+                if (FAST) { d.g = 2.0 / g.gamma; d.afc = g.asym / g.fc; }
+                else { d.g = g.gamma * g.gamma; d.afc = 0.0; }
+#pragma unroll
+                for (int m = 0; m < 7; m++) { d.nu[m] = g.nu[m]; d.hv[m] = g.hv[m]; }
+            }
+            if (tid == 0) s_n = __popcll(mask);
+        }
+        __syncthreads();
+        const int n = s_n;
+        for (int q = 0; q < n; q++) {
+            const LdsMult &M = s_m[q];
+            const int nm = 2 * M.l + 1;
+            const int i0 = M.i0, i1 = M.i1;
+            const double asym = M.asym;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (bin[k] >= i0 && bin[k] < i1) {
+                    const double xx = xv[k];
+                    if (!FAST) {
+                        // reference operation order, one IEEE op per statement
+                        double res = 0.0;
+                        if (asym == 0.0) {
+                            for (int m = 0; m < nm; m++) {
+                                const double d = xx - M.nu[m];
+                                double p = d * d;
+                                p = 4.0 * p / M.g;
+                                const double inv = 1.0 / (1.0 + p);
+                                res = res + M.hv[m] * inv;
+                            }
+                        } else {
+                            const double t = 1.0 + asym * (xx / M.fc - 1.0);
+                            const double asy = t * t + M.c2sq;
+                            for (int m = 0; m < nm; m++) {
+                                const double d = xx - M.nu[m];
+                                double p = d * d;
+                                p = 4.0 * p / M.g;
+                                const double inv = 1.0 / (1.0 + p);
+                                res = res + M.hv[m] * (asy * inv);
+                            }
+                        }
+                        acc[k] = acc[k] + res;
+                    } else {
+                        // sum_m hv_m / q_m accumulated over a common denominator: 3 ops per component
+                        // for q_m, 3 for (N,D), ONE reciprocal per multiplet per bin.
+                        double N = 0.0, D = 1.0;
+                        for (int m = 0; m < nm; m++) {
+                            const double t = (xx - M.nu[m]) * M.g;
+                            const double qq = fma(t, t, 1.0);
+                            N = fma(N, qq, M.hv[m] * D);
+                            D = D * qq;
+                        }
+                        double res;
+                        if (D < 1e290) {
+                            res = N * rcp_nr(D);
+                        } else {  // denominators too large to multiply: plain sum (never taken for sane widths)
+                            res = 0.0;
+                            for (int m = 0; m < nm; m++) {
+                                const double t = (xx - M.nu[m]) * M.g;
+                                res = res + M.hv[m] / fma(t, t, 1.0);
+                            }
+                        }
+                        if (asym != 0.0) {
+                            const double t = fma(M.afc, xx, 1.0 - asym);
+                            res = res * fma(t, t, M.c2sq);
+                        }
+                        acc[k] = acc[k] + res;
+                    }
+                }
+            }
+        }
+    }
+    if (FAST) __syncthreads();  // s_lt visible (also when the evaluation has no multiplet chunk)
+
+    // ---- background + likelihood terms ----
+    double s[2] = {0.0, 0.0};
+    const double white = nz[nn - 1];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double Mv = acc[k];
+        const int bi = min(bin[k], a.Nx - 1);
+        if (!FAST) {
+            for (int h = 0; h < nh; h++) {
+                const double tau = nz[3 * h + 1];
+                if (tau != 0.0) {
+                    double t = pow((1e-3 * tau) * xv[k], nz[3 * h + 2]);
+                    t = nz[3 * h] * (1.0 / (t + 1.0));
+                    Mv = Mv + t;
+                }
+            }
+            Mv = Mv + white;
+            if (bin[k] < a.Nx) {
+                s[0] = s[0] + a.y[bi] * (1.0 / Mv);
+                s[1] = s[1] + log(Mv);
+            }
+        } else {
+            const double lx = a.logx[bi];
+            for (int h = 0; h < nh; h++) {
+                const double tau = nz[3 * h + 1];
+                if (tau != 0.0) {
+                    const double t = exp(nz[3 * h + 2] * (s_lt[h] + lx));
+                    Mv = fma(nz[3 * h], rcp_nr(t + 1.0), Mv);
+                }
+            }
+            Mv = Mv + white;
+            if (bin[k] < a.Nx) s[0] = s[0] + fma(a.y[bi], rcp_nr(Mv), log(Mv));
+        }
+        if (WRITE_MODEL) {
+            if (bin[k] < a.Nx) a.model[(size_t)b * a.Nx + bin[k]] = Mv;
+        }
+    }
+    __syncthreads();
+    double out[2];
+    block_reduce<2>(s, s_red, out);
+    if (tid == 0) {
+        double *p = a.partials + ((size_t)b * a.ntiles + tile) * 2;
+        p[0] = out[0];
+        p[1] = out[1];
+    }
+}
+
+// One workgroup per evaluation: fixed-order sum of the per-tile partials -> S[b] = sum1 + sum2.
+__global__ void __launch_bounds__(WG) k_finalize(const double *partials, int ntiles, double *S) {
+    __shared__ double s_red[2 * (WG / 64)];
+    const int b = blockIdx.x;
+    double s[2] = {0.0, 0.0};
+    for (int t = threadIdx.x; t < ntiles; t += WG) {
+        const double *p = partials + ((size_t)b * ntiles + t) * 2;
+        s[0] = s[0] + p[0];
+        s[1] = s[1] + p[1];
+    }
+    double out[2];
+    block_reduce<2>(s, s_red, out);
+    if (threadIdx.x == 0) S[b] = out[0] + out[1];
+}
+
+template <bool FAST, int K>
+void launch_k(const LoglikeArgs &a, bool write_model, int grid, hipStream_t st) {
+    if (write_model) hipLaunchKernelGGL((k_loglike<FAST, K, true>), dim3(grid), dim3(WG), 0, st, a);
+    else hipLaunchKernelGGL((k_loglike<FAST, K, false>), dim3(grid), dim3(WG), 0, st, a);
+}
+
+}  // namespace
+
+int tile_bins(int K) { return WG * K; }
+
+hipError_t launch_loglike(LoglikeArgs a, bool fast, int K, bool write_model, hipStream_t st) {
+    if (a.B <= 0) return hipSuccess;
+    const int tb = WG * K;
+    a.ntiles = (a.Nx + tb - 1) / tb;
+    const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
+    const long long grid = (long long)ntiles_pad * a.B;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (fast) {
+        if (K == 1) launch_k<true, 1>(a, write_model, (int)grid, st);
+        else if (K == 2) launch_k<true, 2>(a, write_model, (int)grid, st);
+        else launch_k<true, 4>(a, write_model, (int)grid, st);
+    } else {
+        if (K == 1) launch_k<false, 1>(a, write_model, (int)grid, st);
+        else if (K == 2) launch_k<false, 2>(a, write_model, (int)grid, st);
+        else launch_k<false, 4>(a, write_model, (int)grid, st);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const double *partials, int B, int ntiles, double *S, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize, dim3(B), dim3(WG), 0, st, partials, ntiles, S);
+    return hipGetLastError();
+}
+
+}  // namespace tamcmc

@@ -1,0 +1,196 @@
+"""Deterministic synthetic stars for the parity tests and bench.py.
+
+The generators follow the reference's own random-input recipe
+(make_params_aj_model, test/lorentzian_test/unit_tests/test_build_l_mode.cpp:769-874:
+H~U(10,20), Gamma~U(0.5,2), a1~U(0.1,5), |a2|<0.1 a1, ..., inc~U(0,90), trunc_c=50, do_amp=0)
+with fixed seeds.  They only produce parameter vectors / layouts / grids; the spectrum itself is
+y = M(theta_true) * Exp(1) with M supplied by the caller (GPU path in bench.py, oracle in CPU tests).
+"""
+import numpy as np
+
+MODEL_CLASSIC, MODEL_LOCAL, MODEL_AJ = 3, 11, 23
+KEPLER_4YR_RESOL = 1e6 / (4.0 * 365.0 * 86400.0)  # test_build_l_mode.cpp:107
+
+
+def make_params_aj_model(rng, lmax=3, nfreqs=5, dnu=129.5, epsilon=0.02, d0l=-1.3, asym=None, noise=None,
+                         eta_switch=0.0, n_first=0, dl_shift=(0, 0, 0, 0)):
+    """params / plength of model_MS_Global_aj_HarveyLike (layout: SURVEY App. B; models.cpp:1207-1270)."""
+    fl = []
+    for el in range(lmax + 1):
+        for en in range(nfreqs):
+            scatter = rng.uniform(-dnu / 100, dnu / 100)
+            fl.append((n_first + en + dl_shift[el] + epsilon + el / 2.0) * dnu + d0l * el * (el + 1) + scatter)
+    a1 = rng.uniform(0.1, 5.0)
+    aj = np.zeros(13)
+    aj[0] = a1
+    aj[2] = rng.uniform(-0.1 * a1, 0.1 * a1)
+    aj[4] = rng.uniform(-0.025 * a1, 0.025 * a1)
+    aj[6] = rng.uniform(-0.025 * a1, 0.025 * a1)
+    aj[8] = rng.uniform(-0.01 * a1, 0.01 * a1)
+    aj[10] = rng.uniform(-0.005 * a1, 0.005 * a1)
+    aj[12] = eta_switch
+    if asym is None:
+        asym = rng.uniform(-100, 100) if rng.integers(0, 2) == 1 else 0.0
+    vis = np.array([1.5, 0.53, 0.07][:lmax])
+    height = rng.uniform(10, 20, nfreqs)
+    width = rng.uniform(0.5, 2, nfreqs)
+    if noise is None:
+        noise = np.array([0, 1, 1, 0, 1, 1, 0.1])
+    inc = rng.uniform(0.0, 90.0)
+    params = np.concatenate([height, vis, np.array(fl), aj, [asym], width, noise, [inc], [50.0, 0.0]])
+    nfl = [nfreqs if el <= lmax else 0 for el in range(4)]
+    plength = np.array([nfreqs, lmax, nfl[0], nfl[1], nfl[2], nfl[3], 14, nfreqs, len(noise), 1, 2], dtype=np.int32)
+    assert params.size == plength.sum()
+    return params, plength
+
+
+def grid(nx, fmin, step):
+    return fmin + step * np.arange(nx, dtype=np.float64)
+
+
+class Star:
+    """Everything the sampler needs for one star (the content of Config.modeling.inputs + Data)."""
+
+    def __init__(self, model_id, params, plength, x, relax, priors, priors_switch, names, prior_class, extra_priors=None):
+        self.model_id = model_id
+        self.params = np.asarray(params, dtype=np.float64)
+        self.plength = np.asarray(plength, dtype=np.int32)
+        self.x = x
+        self.relax = np.asarray(relax, dtype=np.int32)
+        self.priors = np.asarray(priors, dtype=np.float64)  # 4 x Nparams
+        self.priors_switch = np.asarray(priors_switch, dtype=np.int32)
+        self.names = names
+        self.prior_class = prior_class  # 2 = io_MS_Global, 3 = io_local (Config/default/priors_ctrl.list)
+        self.extra_priors = np.zeros(10) if extra_priors is None else np.asarray(extra_priors, dtype=np.float64)
+        self.y = None
+
+    @property
+    def index_to_relax(self):
+        return np.flatnonzero(self.relax == 1).astype(np.int32)
+
+    @property
+    def nvars(self):
+        return int((self.relax == 1).sum())
+
+    def set_spectrum_from_model(self, model, seed):
+        rng = np.random.default_rng(seed)
+        self.y = np.asarray(model, dtype=np.float64) * rng.exponential(1.0, size=model.size)
+        return self.y
+
+
+# primitive prior ids: Config/default/primepriors_ctrl.list
+P_FIX, P_UNIFORM, P_GAUSS, P_JEFF = 0, 1, 2, 4
+
+
+def _prior_tables(names, params, relax, rules):
+    n = len(names)
+    pr = np.full((4, n), -9999.0)
+    sw = np.zeros(n, dtype=np.int32)
+    for i, nm in enumerate(names):
+        if not relax[i]:
+            continue
+        kind, fn = rules[nm]
+        sw[i] = kind
+        vals = fn(params[i])
+        pr[:len(vals), i] = vals
+    return pr, sw
+
+
+def make_c3_star(seed=20240229, nx=100000, nmax=14, lmax=3, step=0.02, fmin=1950.0):
+    """BASELINE config C3: global MS fit, model_MS_Global_aj_HarveyLike, 14 orders x l<=3 = 56 multiplets,
+    111 parameters (93 free), 1e5 bins of 0.02 muHz over [1950, 3950) muHz, two active Harvey terms."""
+    rng = np.random.default_rng(seed)
+    noise = np.array([1.27, 49.6, 2.0, 2.66, 1.52, 2.0, 0.005])  # test/inputs/Sun/fast/..Priorevalrange.model:94-98
+    params, plength = make_params_aj_model(rng, lmax=lmax, nfreqs=nmax, dnu=135.1, epsilon=0.4, d0l=-1.5, asym=0.0,
+                                           noise=noise, eta_switch=0.0, n_first=15, dl_shift=(0, 0, -1, -1))
+    o_inc = plength[:9].sum()
+    params[o_inc] = 60.0 + rng.uniform(-15, 15)
+    names = (["Height_l0"] * nmax + ["Visibility_l%d" % (l + 1) for l in range(lmax)] + ["Frequency_l"] * (4 * nmax) +
+             ["a1_0", "a1_1", "a2_0", "a2_1", "a3_0", "a3_1", "a4_0", "a4_1", "a5_0", "a5_1", "a6_0", "a6_1", "eta0_switch",
+              "Lorentzian_asymetry"] + ["Width_l0"] * nmax +
+             ["Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p", "Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p",
+              "White_Noise_N0"] + ["Inclination", "Truncation_parameter", "do_amp"])
+    assert len(names) == params.size
+    relax = np.zeros(params.size, dtype=np.int32)
+    relax[:nmax] = 1                                   # heights
+    relax[nmax:nmax + lmax] = 1                        # visibilities
+    relax[nmax + lmax:nmax + lmax + 4 * nmax] = 1      # frequencies
+    o_split = nmax + lmax + 4 * nmax
+    relax[o_split] = 1                                 # a1_0
+    o_w = o_split + 14
+    relax[o_w:o_w + nmax] = 1                          # widths
+    o_n = o_w + nmax
+    relax[[o_n + 3, o_n + 4, o_n + 6]] = 1             # second Harvey H, tc and the white noise
+    relax[o_n] = 1                                     # first Harvey H
+    relax[o_inc] = 1                                   # inclination
+    rules = {
+        "Height_l0": (P_JEFF, lambda v: (1.0, 1.0e4)),
+        "Visibility_l1": (P_GAUSS, lambda v: (1.5, 0.15)),
+        "Visibility_l2": (P_GAUSS, lambda v: (0.53, 0.05)),
+        "Visibility_l3": (P_GAUSS, lambda v: (0.07, 0.02)),
+        "Frequency_l": (P_UNIFORM, lambda v: (v - 8.0, v + 8.0)),
+        "a1_0": (P_UNIFORM, lambda v: (0.0, 8.0)),
+        "Width_l0": (P_JEFF, lambda v: (0.05, 40.0)),
+        "Harvey-Noise_H": (P_UNIFORM, lambda v: (0.0, 50.0)),
+        "Harvey-Noise_tc": (P_UNIFORM, lambda v: (0.0, 100.0)),
+        "White_Noise_N0": (P_UNIFORM, lambda v: (0.0, 5.0)),
+        "Inclination": (P_UNIFORM, lambda v: (0.0, 90.0)),
+    }
+    pr, sw = _prior_tables(names, params, relax, rules)
+    x = grid(nx, fmin, step)
+    # extra_priors (io_ms_global.cpp): [smooth switch, smooth coef, |aj/a1| limits x6, impose_normHnlm, model index 9 = aj]
+    extra = np.array([1.0, 2.0, 0.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.0, 9.0])
+    return Star(MODEL_AJ, params, plength, x, relax, pr, sw, names, prior_class=2, extra_priors=extra)
+
+
+def make_c2_star(seed=20240229, nx=10000):
+    """BASELINE config C2: local slice, model_MS_local_basic, 6 multiplets (l=0,1,2 x 2 orders), 28 parameters
+    (21 free), 1e4 bins at 1-yr resolution from 2900 muHz, white noise only."""
+    rng = np.random.default_rng(seed)
+    step = 1e6 / (365.0 * 86400.0)
+    x = grid(nx, 2900.0, step)
+    dnu, eps = 135.1, 0.45
+    f = []
+    for l, d in ((0, 0.0), (1, -2.5), (2, -9.0)):
+        for n in (21, 22):
+            nn = n - 1 if l == 2 else n
+            f.append((nn + eps + l / 2.0) * dnu + d + rng.uniform(-0.5, 0.5))
+    heights = rng.uniform(10, 20, 6)
+    widths = rng.uniform(0.5, 2, 6)
+    a1, inc = 1.0, 60.0
+    split = [0.0, 0.0, 0.0, np.sqrt(a1) * np.cos(np.radians(inc)), np.sqrt(a1) * np.sin(np.radians(inc)), 0.0]
+    params = np.concatenate([heights, f, split, widths, [0.1], [0.0], [50.0, 0.0]])
+    plength = np.array([6, 0, 2, 2, 2, 0, 6, 6, 1, 1, 2], dtype=np.int32)
+    assert params.size == plength.sum() == 28
+    names = (["Height_l"] * 6 + ["Frequency_l"] * 6 +
+             ["Splitting_a1", "Asphericity_eta", "Splitting_a3", "sqrt(splitting_a1).cosi", "sqrt(splitting_a1).sini",
+              "Lorentzian_asymetry"] + ["Width_l"] * 6 + ["White_Noise_N0", "Inclination", "Truncation_parameter", "do_amp"])
+    relax = np.zeros(28, dtype=np.int32)
+    relax[0:12] = 1
+    relax[[15, 16]] = 1
+    relax[18:24] = 1
+    relax[24] = 1
+    rules = {
+        "Height_l": (P_JEFF, lambda v: (1.0, 1.0e4)),
+        "Frequency_l": (P_UNIFORM, lambda v: (v - 5.0, v + 5.0)),
+        "sqrt(splitting_a1).cosi": (P_UNIFORM, lambda v: (0.0, 2.5)),
+        "sqrt(splitting_a1).sini": (P_UNIFORM, lambda v: (0.0, 2.5)),
+        "Width_l": (P_JEFF, lambda v: (0.05, 40.0)),
+        "White_Noise_N0": (P_UNIFORM, lambda v: (0.0, 5.0)),
+    }
+    pr, sw = _prior_tables(names, params, relax, rules)
+    extra = np.array([0.0, 0.0, 0.2, 0.0, 0, 0, 0, 0, 0, 0])  # priors_local: a3/a1 limit at [2]
+    return Star(MODEL_LOCAL, params, plength, x, relax, pr, sw, names, prior_class=3, extra_priors=extra)
+
+
+def aj_to_classic(params, plength):
+    """Re-packs an aj-layout vector into the Classic (a1, eta, a3, -, -, asym) layout (Nsplit=6)."""
+    nmax, lmax = int(plength[0]), int(plength[1])
+    nf = int(plength[2:6].sum())
+    o = nmax + lmax + nf
+    sp = params[o:o + 14]
+    split = np.array([sp[0], 0.0, sp[4], 0.0, 0.0, sp[13]])
+    out = np.concatenate([params[:o], split, params[o + 14:]])
+    pl = plength.copy()
+    pl[6] = 6
+    return out, pl

@@ -1,0 +1,205 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Tolerances (fp64):
+  STRICT model row : bit-exact when the Harvey pow() terms are inactive; <= 4e-16 relative otherwise (device pow vs libm)
+  FAST   model row : <= 1e-12 relative per bin
+  logL             : <= 1e-12 (STRICT) / 1e-11 (FAST) relative against the 80-bit-accumulated oracle sum;
+                     the reference's own acceptance bound ||dM||_2 <= 1e-8 (test_build_l_mode.cpp:104,134) is the envelope.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctxs(pkg):
+    c = {"strict": pkg.HipContext(0, precision=pkg.PRECISION_STRICT), "fast": pkg.HipContext(0, precision=pkg.PRECISION_FAST)}
+    yield c
+    for v in c.values():
+        v.close()
+
+
+def _spectrum(oracle, star, seed=1):
+    _, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+    return star.set_spectrum_from_model(m0, seed)
+
+
+def _perturbed(star, B, rng, scale=0.01):
+    P = np.tile(star.params, (B, 1))
+    idx = star.index_to_relax
+    P[1:, idx] *= 1.0 + scale * rng.standard_normal((B - 1, idx.size))
+    return P
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("K", [1, 2, 4])
+def test_reference_recipe_strict_bit_exact(pkg, oracle, synth, ctxs, seed, K):
+    rng = np.random.default_rng(200 + seed)
+    lmax = int(rng.integers(2, 4))
+    p, pl = synth.make_params_aj_model(rng, lmax=lmax, nfreqs=5, dnu=rng.uniform(129, 130), epsilon=rng.uniform(0, 0.05),
+                                       d0l=rng.uniform(-2.6, 0))
+    nx = int(np.ceil((5 * 130 + 250) / synth.KEPLER_4YR_RESOL))
+    x = np.linspace(0.0, 5 * 130 + 250.0, nx)
+    st, m_o = oracle.call_model(23, p, pl, x)
+    y = m_o * np.random.default_rng(seed).exponential(1.0, nx)
+    c = ctxs["strict"]
+    c.set_option(pkg.OPT_BINS_PER_THREAD, K)
+    c.set_spectrum(x, y)
+    logL, model, status = c.loglike_params_batch(23, p, pl, want_model=True)
+    assert status[0] == 0
+    assert np.array_equal(model[0], m_o), float(np.max(np.abs(model[0] - m_o)))
+    ref = oracle.chi22p_ld(y, m_o, 1)
+    assert abs(logL[0] - ref) <= 1e-12 * abs(ref)
+    assert np.linalg.norm(model[0] - m_o) <= 1e-8
+    f = ctxs["fast"]
+    f.set_option(pkg.OPT_BINS_PER_THREAD, K)
+    f.set_spectrum(x, y)
+    logLf, modelf, _ = f.loglike_params_batch(23, p, pl, want_model=True)
+    assert np.max(np.abs(modelf[0] - m_o) / m_o) <= 1e-12
+    assert abs(logLf[0] - ref) <= 1e-11 * abs(ref)
+    assert np.linalg.norm(modelf[0] - m_o) <= 1e-8
+
+
+def test_c2_local_batch_tempered(pkg, oracle, synth, ctxs):
+    star = synth.make_c2_star()
+    y = _spectrum(oracle, star)
+    rng = np.random.default_rng(9)
+    B = 10
+    P = _perturbed(star, B, rng)
+    T = 1.7 ** np.arange(B)
+    ref, m_o, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T, want_model=True)
+    for name, tol_m, tol_l in (("strict", 0.0, 1e-12), ("fast", 1e-12, 1e-11)):
+        c = ctxs[name]
+        c.set_option(pkg.OPT_BINS_PER_THREAD, 2)
+        c.set_spectrum(star.x, y)
+        logL, model, status = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0, want_model=True)
+        assert (status == 0).all() and (st_o == 0).all()
+        assert np.max(np.abs(model - m_o) / m_o) <= tol_m
+        for b in range(B):
+            truth = oracle.chi22p_ld(y, m_o[b], 1) / T[b]
+            assert abs(logL[b] - truth) <= tol_l * abs(truth)
+            assert abs(logL[b] - ref[b]) <= 1e-10 * abs(ref[b])
+
+
+def test_c3_like_global_with_harvey_and_asymmetry(pkg, oracle, synth, ctxs):
+    star = synth.make_c3_star(nx=30000, step=2000.0 / 30000)
+    o = star.plength[0] + star.plength[1] + star.plength[2:6].sum()
+    star.params[o + 13] = 25.0   # asymmetry
+    star.params[o + 12] = 1.0    # eta0 on
+    y = _spectrum(oracle, star)
+    rng = np.random.default_rng(10)
+    B = 5
+    P = _perturbed(star, B, rng, 0.003)
+    T = 1.4 ** np.arange(B)
+    ref, m_o, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T, want_model=True)
+    assert (st_o == 0).all()
+    for name, tol_m, tol_l in (("strict", 4e-16, 1e-12), ("fast", 1e-12, 1e-11)):
+        c = ctxs[name]
+        c.set_spectrum(star.x, y)
+        logL, model, status = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0, want_model=True)
+        assert (status == 0).all()
+        assert np.max(np.abs(model - m_o) / m_o) <= tol_m, name
+        for b in range(B):
+            truth = oracle.chi22p_ld(y, m_o[b], 1) / T[b]
+            assert abs(logL[b] - truth) <= tol_l * abs(truth)
+
+
+def test_classic_model_and_p2(pkg, oracle, synth, ctxs):
+    rng = np.random.default_rng(11)
+    p, pl = synth.make_params_aj_model(rng, lmax=3, nfreqs=6, asym=-30.0, n_first=12)
+    pc, plc = synth.aj_to_classic(p, pl)
+    x = synth.grid(50001, 1400.0, 0.02)   # ragged: not a multiple of any tile size
+    _, m_o = oracle.call_model(3, pc, plc, x)
+    y = m_o * np.random.default_rng(2).exponential(1.0, x.size)
+    c = ctxs["strict"]
+    c.set_spectrum(x, y)
+    logL, model, status = c.loglike_params_batch(3, pc, plc, None, 2.0, want_model=True)
+    assert np.array_equal(model[0], m_o)
+    truth = oracle.chi22p_ld(y, m_o, 2)
+    assert abs(logL[0] - truth) <= 1e-12 * abs(truth)
+
+
+def test_table_level_entry_and_empty_table(pkg, oracle, synth, ctxs):
+    """tamcmc_hip_loglike_batch with explicit tables; an evaluation with zero multiplets = background only."""
+    star = synth.make_c2_star(nx=3000)
+    y = _spectrum(oracle, star)
+    st, mults, noise, nh = pkg.build_mode_table(star.model_id, star.params, star.plength, star.x)
+    c = ctxs["strict"]
+    c.set_spectrum(star.x, y)
+    offsets = np.array([0, len(mults), len(mults)], dtype=np.int32)
+    noise2 = np.stack([noise, noise])
+    logL, model = c.loglike_batch(mults, offsets, noise2, [nh, nh], [noise.size, noise.size], None, 1.0, want_model=True)
+    _, m_o = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+    assert np.array_equal(model[0], m_o)
+    assert np.array_equal(model[1], np.full(star.x.size, noise[-1]))
+    truth = -(y / noise[-1] + np.log(noise[-1])).sum()
+    assert logL[1] == pytest.approx(truth, rel=1e-13)
+    with pytest.raises(pkg.TamcmcError):
+        bad = mults.copy()
+        bad["i1"][0] = star.x.size + 5   # window beyond the grid must be refused on the host, never launched
+        c.loglike_batch(bad, offsets, noise2, [nh, nh], [noise.size, noise.size])
+
+
+def test_failed_window_gives_nan_and_status(pkg, oracle, synth, ctxs):
+    star = synth.make_c2_star(nx=3000)
+    y = _spectrum(oracle, star)
+    P = np.tile(star.params, (3, 1))
+    P[1, 18] = np.nan
+    c = ctxs["fast"]
+    c.set_spectrum(star.x, y)
+    logL, _, status = c.loglike_params_batch(star.model_id, P, star.plength)
+    assert status.tolist() == [0, pkg.ERR_NAN_WINDOW, 0]
+    assert np.isnan(logL[1]) and np.isfinite(logL[0]) and logL[0] == logL[2]
+
+
+def test_fd_gradient_matches_oracle(pkg, oracle, synth, ctxs):
+    """The finite-difference gradient has no reference counterpart (MALA::D_MALA is a stub, MALA.cpp:321-328);
+    its oracle is the same forward difference of the CPU log-likelihood."""
+    star = synth.make_c2_star(nx=4000)
+    y = _spectrum(oracle, star)
+    idx = star.index_to_relax
+    h = 1e-6 * np.maximum(np.abs(star.params[idx]), 1.0)
+    _, l0_o, g_o = oracle.fd_gradient(star.model_id, star.params, star.plength, idx, h, star.x, y, 1.0, 1.7)
+    for name, tol in (("strict", 1e-6), ("fast", 1e-5)):
+        c = ctxs[name]
+        c.set_spectrum(star.x, y)
+        l0, g = c.fd_gradient(star.model_id, star.params, star.plength, idx, h, [1.7], 1.0)
+        assert abs(l0[0] - l0_o) <= 1e-11 * abs(l0_o)
+        scale = np.max(np.abs(g_o))
+        assert np.max(np.abs(g[0] - g_o)) <= tol * scale, name
+
+
+def test_full_size_c3_properties(pkg, oracle, synth, ctxs):
+    """BASELINE full size (1e5 bins x 111 params x 20 chains): oracle on 2 chains, plus size-independent properties:
+    identical chains give identical logL (determinism), tempering scales exactly, STRICT vs FAST agree to 1e-11,
+    zero-height modes reduce the model to the background."""
+    star = synth.make_c3_star()
+    y = _spectrum(oracle, star)
+    rng = np.random.default_rng(12)
+    B = 20
+    P = _perturbed(star, B, rng, 0.002)
+    P[7] = P[3]
+    T = 1.35 ** np.arange(B)
+    ref, _, _ = oracle.loglike_batch(star.model_id, P[:2], star.plength, star.x, y, 1.0, T[:2])
+    out = {}
+    for name in ("strict", "fast"):
+        c = ctxs[name]
+        c.set_option(pkg.OPT_BINS_PER_THREAD, 2)
+        c.set_spectrum(star.x, y)
+        logL, _, status = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0)
+        logL1, _, _ = c.loglike_params_batch(star.model_id, P, star.plength, None, 1.0)
+        assert (status == 0).all()
+        assert np.allclose(logL[:2], ref, rtol=1e-11, atol=0)
+        assert logL1[7] == logL1[3]
+        assert np.allclose(logL, logL1 / T, rtol=4e-16, atol=0)
+        again, _, _ = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0)
+        assert np.array_equal(again, logL)
+        out[name] = logL
+    assert np.max(np.abs(out["fast"] - out["strict"]) / np.abs(out["strict"])) <= 1e-11
+    P0 = star.params.copy()
+    P0[:14] = 0.0
+    c = ctxs["strict"]
+    _, model, _ = c.loglike_params_batch(star.model_id, P0, star.plength, want_model=True)
+    nz = np.abs(star.params[star.plength[:8].sum():star.plength[:9].sum()])
+    bg = nz[0] / (1 + (1e-3 * nz[1] * star.x) ** nz[2]) + nz[3] / (1 + (1e-3 * nz[4] * star.x) ** nz[5]) + nz[6]
+    assert np.max(np.abs(model[0] - bg) / bg) < 1e-14
