@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- MCMC samples/s of the MI355X hot path on BASELINE.json's headline configuration.
+
+One "step" = one MCMC iteration of one star = ALL tempered chains advanced once
+(propose -> batched Lorentzian-sum model + chi^2(2 d.o.f.) log-likelihood on the GPU -> accept -> PT swap),
+i.e. the reference's loop counter i (MALA.cpp:623,743).  Workload at N=1: configs[2] (C3) of BASELINE.json:
+global MS fit, model_MS_Global_aj_HarveyLike, 1e5 bins x 111 parameters (93 free) x 20 tempered chains, synthetic star.
+N>1 (torchrun, one rank per GPU): one independent star per GPU, no data-path collective -> weak scaling;
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+
+The spectrum is resident in HBM before the timed region; per-step host->device traffic is the chains' mode tables
+(~170 KB) -- the boundary hands over host parameter vectors, like Model_def::generate_model does.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # vector fp64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--chains", type=int, default=20)
+    ap.add_argument("--nx", type=int, default=100000)
+    ap.add_argument("--precision", choices=["fast", "strict"], default="fast")
+    ap.add_argument("--sampler", choices=["mh", "mala"], default="mh",
+                    help="mh = adaptive random-walk MH + PT (what the reference runs); mala = Langevin drift, FD gradient")
+    ap.add_argument("--mala-steps", type=int, default=30, help="extra MALA-FD measurement (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(star, y, nchains, lam, budget_s):
+    """The CPU restatement (oracle, -O3 build, OpenMP over chains like MALA.cpp:648) timed on the same workload:
+    repeated batches of `nchains` model+logL evaluations = the hot-path share of one MCMC iteration."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    cores = min(nchains, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    orc = oracle_lib.Oracle(fast=True)
+    rng = np.random.default_rng(1)
+    P = np.tile(star.params, (nchains, 1))
+    idx = star.index_to_relax
+    P[1:, idx] *= 1.0 + 0.002 * rng.standard_normal((nchains - 1, idx.size))
+    T = lam ** np.arange(nchains)
+    orc.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return {"value": n / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} batches of {nchains} chain evaluations (model_MS_Global_aj_HarveyLike + chi22p, Nx={star.x.size}) "
+                      f"in {el:.1f} s; oracle/tamcmc_oracle.c -O3 -march=x86-64-v3, OpenMP over chains as MALA.cpp:648; "
+                      "hot path only (no proposal/Cholesky/output cost), so it flatters the CPU"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    pkg = entry.load_package()
+    from tamcmc_c_amd import synth
+
+    lam = 1.3
+    star = synth.make_c3_star(seed=20240229 + rank, nx=a.nx, step=2000.0 / a.nx)
+    prec = pkg.PRECISION_FAST if a.precision == "fast" else pkg.PRECISION_STRICT
+    ctx = pkg.HipContext(local_rank, precision=prec, timing=True)
+    # synthetic spectrum y = M(theta_true) * Exp(1): the model row comes from the GPU path itself (STRICT arithmetic)
+    ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_STRICT)
+    ctx.set_spectrum(star.x, np.ones_like(star.x))
+    _, m0, _ = ctx.loglike_params_batch(star.model_id, star.params, star.plength, want_model=True)
+    y = star.set_spectrum_from_model(m0[0], seed=20240301 + rank)
+    ctx.set_option(pkg.OPT_PRECISION, prec)
+    ctx.set_spectrum(star.x, y)
+
+    def make_sampler(use_drift, learn_until):
+        return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank,
+                           Nt_learn=(max(learn_until // 2, 1), max(learn_until, 2)), periods_learn=(1,), dN_mixing=1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    smp = make_sampler(1 if a.sampler == "mala" else 0, a.warmup)
+    smp.run(a.warmup, record=False)
+    ctx.reset_kernel_stats()
+    acc0 = smp.state()
+    barrier()
+    t0 = time.perf_counter()
+    smp.run(a.steps, record=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches, k_evals = ctx.kernel_stats()
+    st = smp.state()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * a.steps / elapsed
+
+    extra = {}
+    if a.mala_steps > 0 and a.sampler == "mh" and world == 1:
+        ms = make_sampler(1, 10)
+        ms.run(5, record=False)
+        ctx.reset_kernel_stats()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ms.run(a.mala_steps, record=False)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        mk_ms, mk_l, mk_e = ctx.kernel_stats()
+        extra["mala_fd"] = {"samples_per_s": a.mala_steps / e1, "steps": a.mala_steps,
+                            "evals_per_step": mk_e / a.mala_steps, "kernel_us_per_launch": mk_ms / max(mk_l, 1) * 1e3,
+                            "alg_GBps": 16.0 * a.nx * mk_e / max(mk_ms * 1e-3, 1e-12) / 1e9}
+        ms.close()
+
+    if rank == 0:
+        st_tab, mults, _, _ = pkg.build_mode_table(star.model_id, star.params, star.plength, star.x)
+        W = int(((mults["i1"] - mults["i0"]) * (2 * mults["l"] + 1)).sum())
+        evals_per_launch = k_evals / max(k_launches, 1)
+        k_s = k_ms * 1e-3 / max(k_launches, 1)
+        alg_bytes = 16.0 * a.nx * evals_per_launch          # B_eval = 16*Nx bytes per evaluation
+        achieved = alg_bytes / k_s / 1e9
+        out = {
+            "metric": "MCMC samples/sec (whole node), 1e5 nu-bins x 100 params x 20 tempered chains",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C3 global MS fit: model_MS_Global_aj_HarveyLike, Nx={a.nx}, 111 params ({star.nvars} free), "
+                                   f"{len(mults)} multiplets, {a.chains} tempered chains (lambda={lam}), one star per GPU",
+                       "sampler": "adaptive random-walk MH + parallel tempering (use_drift=0, the reference's sampler)"
+                       if a.sampler == "mh" else "Langevin drift, forward-difference gradient (use_drift=1)",
+                       "arithmetic": a.precision, "component_bin_evals_per_model": W},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_loglike",
+                         "kernel_us_per_launch": k_s * 1e6, "evaluations_per_launch": evals_per_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "fp64_valu": {"component_evals_per_s": W * evals_per_launch / k_s,
+                                       "note": "the path is fp64-VALU(divide)-bound: ~80-110 component evaluations per 16 B"}},
+            "accept_rate_chain0": (st["accepted0"] - acc0["accepted0"]) / max(a.steps, 1),
+            "swap_rate": st["swaps"] / max(st["swap_attempts"], 1),
+            "kernel_time_fraction": k_ms * 1e-3 / elapsed,
+        }
+        out.update(extra)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(star, y, a.chains, lam, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    smp.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+/*
+ * tamcmc_sampler.h -- C ABI of the sampler that calls the hot path (host-side mirror of the reference's
+ * MALA + Model_def classes, tamcmc/sources/MALA.cpp, tamcmc/sources/model_def.cpp).
+ *
+ * The reference drives the hot path from MALA::execute (MALA.cpp:555-747): per iteration, for every tempered chain,
+ * propose -> Model_def::generate_model -> accept; then Robbins-Monro adaptation and a parallel-tempering swap.
+ * tamcmc_sampler_run() is that loop with the chains batched into one device call per iteration.
+ * The configuration struct carries what Config::setup (config.cpp:167-396) would have produced from the
+ * .cfg/.model/.data files: Input_Data{inputs, relax, priors, plength, extra_priors} and the !MALA section.
+ */
+#ifndef TAMCMC_SAMPLER_H
+#define TAMCMC_SAMPLER_H
+
+#include <stdint.h>
+
+#include "tamcmc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tamcmc_sampler tamcmc_sampler;
+
+typedef struct tamcmc_sampler_config {
+    /* modeling (config_default.cfg !Modeling; ids from Config/default/{models,priors,likelihoods}_ctrl.list) */
+    int32_t model_id;        /* model_fct_name_switch: 3, 11, 23 */
+    int32_t prior_class;     /* prior_fct_name_switch: 2 = io_MS_Global, 3 = io_local */
+    int32_t likelihood_id;   /* 0 = chi(2,2p) */
+    int32_t use_drift;       /* 0 = adaptive random-walk MH (the reference), 1 = Langevin drift with FD gradient */
+    double likelihood_params;/* p */
+    int64_t Nparams;
+    const double *inputs;          /* [Nparams] initial parameter vector */
+    const int32_t *relax;          /* [Nparams] 1 = free */
+    const int32_t *plength;        /* [11] */
+    const double *priors;          /* [4 x Nparams] row-major */
+    const int32_t *priors_switch;  /* [Nparams] primitive prior ids (primepriors_ctrl.list) */
+    const double *extra_priors;    /* [n_extra] */
+    int32_t n_extra;
+    /* !MALA section */
+    int32_t Nchains;
+    double lambda_temp, target_acceptance, c0, epsilon1, epsilon2, A1, delta, delta_x;
+    const int64_t *Nt_learn;       /* [n_Nt_learn] */
+    const int64_t *periods_learn;  /* [n_Nt_learn-1] */
+    int32_t n_Nt_learn;
+    int32_t reserved0;
+    int64_t dN_mixing;
+    const double *init_errors;     /* [Nvars] initial proposal standard deviations (errors_default.cfg), NULL -> 1 */
+    /* additions of this build */
+    uint64_t seed;                 /* counter-based RNG seed (the reference seeds libc rand() with time(NULL)) */
+    double fd_step_rel;            /* forward-difference step = fd_step_rel * max(|theta_k|, 1e-3); 0 -> 1e-7 */
+} tamcmc_sampler_config;
+
+/* The context must already hold the spectrum (tamcmc_hip_set_spectrum). It is borrowed, not owned. */
+int tamcmc_sampler_create(tamcmc_sampler **s, tamcmc_hip_ctx *ctx, const tamcmc_sampler_config *cfg);
+void tamcmc_sampler_destroy(tamcmc_sampler *s);
+int64_t tamcmc_sampler_nvars(const tamcmc_sampler *s);
+
+/* Advances all chains by n_iter iterations.  Optional outputs, one record per iteration after the swap step
+ * (what update_buffer_params / update_buffer_stat_criteria record, MALA.cpp:708-710):
+ *   samples : [n_iter x Nchains x Nvars]      stats : [n_iter x Nchains x 3] = logL (tempered), logPrior, logPosterior */
+int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, double *stats);
+
+/* Current state. Any pointer may be NULL.
+ *   vars [Nchains x Nvars], logL/logPrior/logPost/Pmove/sigma [Nchains], counters [4] = iteration, accepted moves
+ *   of chain 0, swap attempts, swaps accepted */
+int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL, double *logPrior, double *logPost,
+                             double *Pmove, double *sigma, int64_t *counters);
+/* proposal law of chain m: mu [Nvars], covarmat [Nvars x Nvars] (restore file content, outputs.cpp:863-1025) */
+int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, double *covarmat);
+int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, const double *covarmat, double sigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -198,3 +198,7 @@ class HipContext:
 
     def reset_kernel_stats(self):
         self._chk(self._L.tamcmc_hip_reset_kernel_stats(self._h))
+
+
+from . import sampler  # noqa: E402,F401  (registers the tamcmc_sampler_* symbols in EXTRA_ABI)
+from .sampler import Sampler  # noqa: E402,F401

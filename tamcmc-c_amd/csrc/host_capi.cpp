@@ -1,0 +1,137 @@
+// host_capi.cpp -- C ABI of include/tamcmc_sampler.h over the host-side Model_def / MALA mirrors.
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/tamcmc_sampler.h"
+#include "host_sampler.h"
+
+using namespace tamcmc;
+
+struct tamcmc_sampler {
+    Config cfg;
+    std::unique_ptr<MALA> mala;
+    std::unique_ptr<Model_def> cur, prop;
+    long accepted0 = 0;
+};
+
+extern "C" {
+
+int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcmc_sampler_config *c) {
+    if (!out || !ctx || !c || !c->inputs || !c->relax || !c->plength || !c->priors || !c->priors_switch) return TAMCMC_ERR_BAD_ARG;
+    if (c->Nchains < 1 || c->Nparams < 1) return TAMCMC_ERR_BAD_ARG;
+    *out = nullptr;
+    auto s = std::make_unique<tamcmc_sampler>();
+    Config &g = s->cfg;
+    g.modeling.model_fct_name_switch = c->model_id;
+    g.modeling.prior_fct_name_switch = c->prior_class;
+    g.modeling.likelihood_fct_name_switch = c->likelihood_id;
+    g.modeling.likelihood_params = c->likelihood_params;
+    Input_Data &in = g.modeling.inputs;
+    const size_t Np = (size_t)c->Nparams;
+    in.inputs.assign(c->inputs, c->inputs + Np);
+    in.relax.assign(c->relax, c->relax + Np);
+    in.plength.assign(c->plength, c->plength + 11);
+    long psum = 0;
+    for (int v : in.plength) psum += v;
+    if (psum != c->Nparams) return TAMCMC_ERR_BAD_ARG;
+    in.priors = Matrix(4, c->Nparams);
+    std::memcpy(in.priors.a.data(), c->priors, 4 * Np * sizeof(double));
+    in.priors_names_switch.assign(c->priors_switch, c->priors_switch + Np);
+    in.extra_priors.assign(10, 0.0);
+    for (int i = 0; i < c->n_extra && i < 10; i++) in.extra_priors[(size_t)i] = c->extra_priors[i];
+    long nv = 0;
+    for (size_t i = 0; i < Np; i++) {
+        in.inputs_names.push_back("p" + std::to_string(i));
+        if (in.relax[i] == 1) {
+            g.MALA.var_names_errors.push_back(in.inputs_names.back());
+            g.MALA.fraction_errors.push_back(0.0);
+            g.MALA.offset_errors.push_back(c->init_errors ? c->init_errors[nv] : 1.0);
+            nv++;
+        }
+    }
+    if (nv < 1) return TAMCMC_ERR_BAD_ARG;
+    g.MALA.Nchains = c->Nchains;
+    g.MALA.lambda_temp = c->lambda_temp;
+    g.MALA.target_acceptance = c->target_acceptance;
+    g.MALA.c0 = c->c0;
+    g.MALA.epsilon1 = c->epsilon1;
+    g.MALA.epsi2 = c->epsilon2;
+    g.MALA.A1 = c->A1;
+    g.MALA.delta = c->delta;
+    g.MALA.delta_x = c->delta_x;
+    g.MALA.Nt_learn.assign(c->Nt_learn, c->Nt_learn + (c->Nt_learn ? c->n_Nt_learn : 0));
+    g.MALA.periods_learn.assign(c->periods_learn, c->periods_learn + (c->periods_learn && c->n_Nt_learn > 0 ? c->n_Nt_learn - 1 : 0));
+    g.MALA.dN_mixing = c->dN_mixing;
+    g.MALA.use_drift = c->use_drift;
+    g.MALA.seed = c->seed;
+    g.MALA.fd_step_rel = c->fd_step_rel > 0 ? c->fd_step_rel : 1e-7;
+    s->mala = std::make_unique<MALA>(&g);
+    s->cur = std::make_unique<Model_def>(&g, s->mala->Tcoefs, false, ctx);
+    if (s->cur->last_status != TAMCMC_OK) return s->cur->last_status;
+    s->prop = std::make_unique<Model_def>(*s->cur);
+    *out = s.release();
+    return TAMCMC_OK;
+}
+
+void tamcmc_sampler_destroy(tamcmc_sampler *s) { delete s; }
+
+int64_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->cur->get_Nvars() : -1; }
+
+int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, double *stats) {
+    if (!s || n_iter < 0) return TAMCMC_ERR_BAD_ARG;
+    const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    for (int64_t it = 0; it < n_iter; it++) {
+        int rc = s->mala->step(s->cur.get(), s->prop.get(), &s->cfg.data.data, &s->cfg);
+        if (rc) return rc;
+        s->accepted0 += s->cur->moved[0] ? 1 : 0;
+        if (samples) std::memcpy(samples + (size_t)it * Nc * Nv, s->cur->vars.a.data(), (size_t)(Nc * Nv) * sizeof(double));
+        if (stats)
+            for (long m = 0; m < Nc; m++) {
+                double *r = stats + ((size_t)it * Nc + (size_t)m) * 3;
+                r[0] = s->cur->logLikelihood[(size_t)m];
+                r[1] = s->cur->logPrior[(size_t)m];
+                r[2] = s->cur->logPosterior[(size_t)m];
+            }
+    }
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL, double *logPrior, double *logPost,
+                             double *Pmove, double *sigma, int64_t *counters) {
+    if (!s) return TAMCMC_ERR_BAD_ARG;
+    const size_t Nc = (size_t)s->cfg.MALA.Nchains;
+    if (vars) std::memcpy(vars, s->cur->vars.a.data(), s->cur->vars.a.size() * sizeof(double));
+    if (logL) std::memcpy(logL, s->cur->logLikelihood.data(), Nc * sizeof(double));
+    if (logPrior) std::memcpy(logPrior, s->cur->logPrior.data(), Nc * sizeof(double));
+    if (logPost) std::memcpy(logPost, s->cur->logPosterior.data(), Nc * sizeof(double));
+    if (Pmove) std::memcpy(Pmove, s->cur->Pmove.data(), Nc * sizeof(double));
+    if (sigma) std::memcpy(sigma, s->mala->sigma.data(), Nc * sizeof(double));
+    if (counters) {
+        counters[0] = s->mala->iteration;
+        counters[1] = s->accepted0;
+        counters[2] = s->mala->Nswap_attempts;
+        counters[3] = s->mala->Nswap_accepted;
+    }
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, double *covarmat) {
+    if (!s || m < 0 || m >= s->cfg.MALA.Nchains) return TAMCMC_ERR_BAD_ARG;
+    const long Nv = s->cur->get_Nvars();
+    if (mu) std::memcpy(mu, s->mala->mu.row(m), (size_t)Nv * sizeof(double));
+    if (covarmat) std::memcpy(covarmat, s->mala->covarmat[(size_t)m].a.data(), (size_t)(Nv * Nv) * sizeof(double));
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, const double *covarmat, double sigma) {
+    if (!s || m < 0 || m >= s->cfg.MALA.Nchains) return TAMCMC_ERR_BAD_ARG;
+    const long Nv = s->cur->get_Nvars();
+    if (mu) std::memcpy(s->mala->mu.row(m), mu, (size_t)Nv * sizeof(double));
+    if (covarmat) std::memcpy(s->mala->covarmat[(size_t)m].a.data(), covarmat, (size_t)(Nv * Nv) * sizeof(double));
+    if (sigma > 0) s->mala->sigma[(size_t)m] = sigma;
+    s->mala->invalidate(m);
+    return TAMCMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+"""ctypes binding of include/tamcmc_sampler.h (the host-side mirror of the reference's MALA + Model_def)."""
+import ctypes as C
+
+import numpy as np
+
+from . import ABI, EXTRA_ABI, HipContext, TamcmcError, OK, lib, _dp, _ip, _vp, _f64, _i32, _p
+
+_i64p = C.POINTER(C.c_int64)
+
+
+class SamplerConfig(C.Structure):
+    """struct tamcmc_sampler_config"""
+    _fields_ = [("model_id", C.c_int32), ("prior_class", C.c_int32), ("likelihood_id", C.c_int32), ("use_drift", C.c_int32),
+                ("likelihood_params", C.c_double), ("Nparams", C.c_int64), ("inputs", _dp), ("relax", _ip), ("plength", _ip),
+                ("priors", _dp), ("priors_switch", _ip), ("extra_priors", _dp), ("n_extra", C.c_int32),
+                ("Nchains", C.c_int32), ("lambda_temp", C.c_double), ("target_acceptance", C.c_double), ("c0", C.c_double),
+                ("epsilon1", C.c_double), ("epsilon2", C.c_double), ("A1", C.c_double), ("delta", C.c_double),
+                ("delta_x", C.c_double), ("Nt_learn", _i64p), ("periods_learn", _i64p), ("n_Nt_learn", C.c_int32),
+                ("reserved0", C.c_int32), ("dN_mixing", C.c_int64), ("init_errors", _dp), ("seed", C.c_uint64),
+                ("fd_step_rel", C.c_double)]
+
+
+EXTRA_ABI += [
+    ("tamcmc_sampler_create", C.c_int, [C.POINTER(_vp), _vp, C.POINTER(SamplerConfig)]),
+    ("tamcmc_sampler_destroy", None, [_vp]),
+    ("tamcmc_sampler_nvars", C.c_int64, [_vp]),
+    ("tamcmc_sampler_run", C.c_int, [_vp, C.c_int64, _dp, _dp]),
+    ("tamcmc_sampler_get_state", C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _i64p]),
+    ("tamcmc_sampler_get_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp]),
+    ("tamcmc_sampler_set_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_double]),
+]
+
+
+def _rebind():
+    L = lib()
+    for name, res, args in EXTRA_ABI:
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    return L
+
+
+class Sampler:
+    """Parallel-tempered adaptive MH / Langevin sampler of one star on one GPU context.
+
+    Defaults follow Config/default/config_default.cfg (!MALA section)."""
+
+    def __init__(self, ctx: HipContext, star, nchains=5, lambda_temp=3.5, use_drift=0, seed=20240229, p=1.0,
+                 target_acceptance=0.234, c0=10.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, delta=0.0, delta_x=1e-10,
+                 Nt_learn=(1000, 1500, 100000), periods_learn=(1, 1), dN_mixing=1, init_errors=None, fd_step_rel=1e-7):
+        self._L = _rebind()
+        self.ctx = ctx
+        self.nchains = int(nchains)
+        keep = self._keep = {}
+        keep["inputs"] = _f64(star.params)
+        keep["relax"] = _i32(star.relax)
+        keep["plength"] = _i32(star.plength)
+        keep["priors"] = _f64(star.priors)
+        keep["sw"] = _i32(star.priors_switch)
+        keep["extra"] = _f64(star.extra_priors)
+        keep["Nt"] = np.ascontiguousarray(Nt_learn, dtype=np.int64)
+        keep["per"] = np.ascontiguousarray(periods_learn, dtype=np.int64)
+        nv = int((keep["relax"] == 1).sum())
+        if init_errors is None:
+            init_errors = default_errors(star)
+        keep["err"] = _f64(init_errors)
+        assert keep["err"].size == nv
+        cfg = SamplerConfig()
+        cfg.model_id, cfg.prior_class, cfg.likelihood_id, cfg.use_drift = int(star.model_id), int(star.prior_class), 0, int(use_drift)
+        cfg.likelihood_params, cfg.Nparams = float(p), keep["inputs"].size
+        cfg.inputs, cfg.relax, cfg.plength = _p(keep["inputs"]), _p(keep["relax"], _ip), _p(keep["plength"], _ip)
+        cfg.priors, cfg.priors_switch = _p(keep["priors"]), _p(keep["sw"], _ip)
+        cfg.extra_priors, cfg.n_extra = _p(keep["extra"]), keep["extra"].size
+        cfg.Nchains, cfg.lambda_temp, cfg.target_acceptance, cfg.c0 = self.nchains, lambda_temp, target_acceptance, c0
+        cfg.epsilon1, cfg.epsilon2, cfg.A1, cfg.delta, cfg.delta_x = epsilon1, epsilon2, A1, delta, delta_x
+        cfg.Nt_learn, cfg.periods_learn, cfg.n_Nt_learn = _p(keep["Nt"], _i64p), _p(keep["per"], _i64p), keep["Nt"].size
+        cfg.dN_mixing, cfg.init_errors, cfg.seed, cfg.fd_step_rel = int(dN_mixing), _p(keep["err"]), int(seed), fd_step_rel
+        h = _vp()
+        st = self._L.tamcmc_sampler_create(C.byref(h), ctx._h, C.byref(cfg))
+        if st != OK:
+            raise TamcmcError(st, "tamcmc_sampler_create: " + self._L.tamcmc_hip_last_error(ctx._h).decode())
+        self._h = h
+        self.nvars = int(self._L.tamcmc_sampler_nvars(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tamcmc_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, n_iter, record=True, stats=False):
+        n_iter = int(n_iter)
+        smp = np.zeros((n_iter, self.nchains, self.nvars)) if record else None
+        stt = np.zeros((n_iter, self.nchains, 3)) if stats else None
+        st = self._L.tamcmc_sampler_run(self._h, n_iter, _p(smp), _p(stt))
+        if st != OK:
+            raise TamcmcError(st, self._L.tamcmc_hip_last_error(self.ctx._h).decode())
+        return smp, stt
+
+    def state(self):
+        nc, nv = self.nchains, self.nvars
+        out = {"vars": np.zeros((nc, nv)), "logL": np.zeros(nc), "logPrior": np.zeros(nc), "logPost": np.zeros(nc),
+               "Pmove": np.zeros(nc), "sigma": np.zeros(nc)}
+        cnt = np.zeros(4, dtype=np.int64)
+        self._L.tamcmc_sampler_get_state(self._h, _p(out["vars"]), _p(out["logL"]), _p(out["logPrior"]), _p(out["logPost"]),
+                                         _p(out["Pmove"]), _p(out["sigma"]), _p(cnt, _i64p))
+        out.update(iteration=int(cnt[0]), accepted0=int(cnt[1]), swap_attempts=int(cnt[2]), swaps=int(cnt[3]))
+        return out
+
+    def get_proposal(self, m):
+        mu, cov = np.zeros(self.nvars), np.zeros((self.nvars, self.nvars))
+        self._L.tamcmc_sampler_get_proposal(self._h, int(m), _p(mu), _p(cov))
+        return mu, cov
+
+    def set_proposal(self, m, mu=None, cov=None, sigma=0.0):
+        mu = _f64(mu) if mu is not None else None
+        cov = _f64(cov) if cov is not None else None
+        self._L.tamcmc_sampler_set_proposal(self._h, int(m), _p(mu), _p(cov), float(sigma))
+
+
+def default_errors(star):
+    """Initial proposal standard deviations per free parameter, in the spirit of Config/default/errors_default.cfg
+    (error = fraction*value + offset per parameter family)."""
+    rules = {"Height": (0.05, 0.0), "Visibility": (0.03, 0.0), "Frequency": (0.0, 0.05), "Width": (0.05, 0.0),
+             "a1_0": (0.05, 0.01), "sqrt(splitting_a1)": (0.03, 0.01), "Harvey-Noise_H": (0.02, 0.0),
+             "Harvey-Noise_tc": (0.02, 0.0), "White_Noise_N0": (0.01, 0.0), "Inclination": (0.0, 1.0)}
+    err = []
+    for i in np.flatnonzero(star.relax == 1):
+        nm = star.names[i]
+        frac, off = 0.02, 1e-3
+        for key, (f, o) in rules.items():
+            if nm.startswith(key):
+                frac, off = f, o
+        err.append(abs(star.params[i]) * frac + off)
+    return np.array(err)

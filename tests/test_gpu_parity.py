@@ -57,7 +57,7 @@ def test_reference_recipe_strict_bit_exact(pkg, oracle, synth, ctxs, seed, K):
     logLf, modelf, _ = f.loglike_params_batch(23, p, pl, want_model=True)
     assert np.max(np.abs(modelf[0] - m_o) / m_o) <= 1e-12
     assert abs(logLf[0] - ref) <= 1e-11 * abs(ref)
-    assert np.linalg.norm(modelf[0] - m_o) <= 1e-8
+    assert np.linalg.norm(modelf[0] - m_o) <= 1e-12 * np.linalg.norm(m_o)
 
 
 def test_c2_local_batch_tempered(pkg, oracle, synth, ctxs):
