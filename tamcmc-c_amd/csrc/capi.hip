@@ -73,17 +73,30 @@ struct tamcmc_hip_ctx {
     int64_t Nx = 0;
     std::vector<double> hx;  // host copy of x (table builders need x[0], x[Nx-1], step)
     DevBuf<double> dx, dy, dlogx;
-    // staging
-    DevBuf<tamcmc_multiplet> d_mults;
-    DevBuf<int32_t> d_off, d_nh, d_nn;
-    DevBuf<double> d_noise, d_part, d_S, d_model;
-    PinBuf<tamcmc_multiplet> h_mults;
-    PinBuf<int32_t> h_off, h_nh, h_nn;
-    PinBuf<double> h_noise, h_S;
+    // ONE pinned staging block and its device image per call (a single H2D copy):
+    //   [int32 begin/end pairs 2B | int32 nharvey B | int32 nnoise B | pad] [double noise B*stride] [multiplets]
+    PinBuf<unsigned char> h_stage;
+    DevBuf<unsigned char> d_stage;
+    DevBuf<double> d_part, d_S, d_model;
+    PinBuf<double> h_S;
     // stats
     double kernel_ms = 0;
     int64_t launches = 0, evals = 0;
 };
+
+namespace {
+struct StageLayout {
+    size_t off_pairs, off_nh, off_nn, off_noise, off_mults, bytes;
+    StageLayout(int B, int stride, size_t total_mults) {
+        off_pairs = 0;
+        off_nh = off_pairs + (size_t)2 * B * sizeof(int32_t);
+        off_nn = off_nh + (size_t)B * sizeof(int32_t);
+        off_noise = (off_nn + (size_t)B * sizeof(int32_t) + 15) & ~(size_t)15;
+        off_mults = (off_noise + (size_t)B * stride * sizeof(double) + 15) & ~(size_t)15;
+        bytes = off_mults + (total_mults + 1) * sizeof(tamcmc_multiplet);
+    }
+};
+}  // namespace
 
 #define HIPCHK(ctx, call)                                                                     \
     do {                                                                                      \
@@ -120,10 +133,8 @@ void tamcmc_hip_destroy(tamcmc_hip_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->dx.release(); c->dy.release(); c->dlogx.release();
-    c->d_mults.release(); c->d_off.release(); c->d_nh.release(); c->d_nn.release();
-    c->d_noise.release(); c->d_part.release(); c->d_S.release(); c->d_model.release();
-    c->h_mults.release(); c->h_off.release(); c->h_nh.release(); c->h_nn.release();
-    c->h_noise.release(); c->h_S.release();
+    c->h_stage.release(); c->d_stage.release();
+    c->d_part.release(); c->d_S.release(); c->d_model.release(); c->h_S.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -165,33 +176,30 @@ int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *c, const double *x, const double *y,
     return TAMCMC_OK;
 }
 
-// Launch on tables already staged in the pinned buffers h_mults/h_off/h_nh/h_nn/h_noise.
-static int run_staged(tamcmc_hip_ctx *c, int B, size_t total_mults, int noise_stride, const double *Tcoefs, double p,
+// Launch on the tables staged in c->h_stage (layout L).
+static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_stride, const double *Tcoefs, double p,
                       double *logL, double *model) {
     const int Nx = (int)c->Nx;
     const int tb = tamcmc::tile_bins(c->K);
     const int ntiles = (Nx + tb - 1) / tb;
-    HIPCHK(c, c->d_mults.reserve(total_mults + 1));
-    HIPCHK(c, c->d_off.reserve((size_t)B + 1));
-    HIPCHK(c, c->d_nh.reserve((size_t)B));
-    HIPCHK(c, c->d_nn.reserve((size_t)B));
-    HIPCHK(c, c->d_noise.reserve((size_t)B * noise_stride));
+    HIPCHK(c, c->d_stage.reserve(L.bytes));
     HIPCHK(c, c->d_part.reserve((size_t)B * ntiles * 2));
     HIPCHK(c, c->d_S.reserve((size_t)B));
     HIPCHK(c, c->h_S.reserve((size_t)B));
     if (model) HIPCHK(c, c->d_model.reserve((size_t)B * Nx));
     hipStream_t st = c->stream;
-    if (total_mults)
-        HIPCHK(c, hipMemcpyAsync(c->d_mults.p, c->h_mults.p, total_mults * sizeof(tamcmc_multiplet), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_off.p, c->h_off.p, ((size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_nh.p, c->h_nh.p, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_nn.p, c->h_nn.p, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_noise.p, c->h_noise.p, (size_t)B * noise_stride * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage.p, L.bytes, hipMemcpyHostToDevice, st));
 
     tamcmc::LoglikeArgs a;
     a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.B = B; a.ntiles = ntiles;
-    a.mults = c->d_mults.p; a.offsets = c->d_off.p; a.noise = c->d_noise.p; a.noise_stride = noise_stride;
-    a.nharvey = c->d_nh.p; a.nnoise = c->d_nn.p; a.partials = c->d_part.p; a.model = model ? c->d_model.p : nullptr;
+    a.mults = (const tamcmc_multiplet *)(c->d_stage.p + L.off_mults);
+    a.offsets = (const int32_t *)(c->d_stage.p + L.off_pairs);
+    a.noise = (const double *)(c->d_stage.p + L.off_noise);
+    a.noise_stride = noise_stride;
+    a.nharvey = (const int32_t *)(c->d_stage.p + L.off_nh);
+    a.nnoise = (const int32_t *)(c->d_stage.p + L.off_nn);
+    a.partials = c->d_part.p;
+    a.model = model ? c->d_model.p : nullptr;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
     HIPCHK(c, tamcmc::launch_loglike(a, c->precision == TAMCMC_PRECISION_FAST, c->K, model != nullptr, st));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));
@@ -238,52 +246,57 @@ int tamcmc_hip_loglike_batch(tamcmc_hip_ctx *c, int B, const tamcmc_multiplet *m
         const tamcmc_multiplet &m = mults[i];
         if (m.l < 0 || m.l > 3 || m.i0 < 0 || m.i1 > c->Nx || m.i1 <= m.i0) return TAMCMC_ERR_BAD_ARG;
     }
-    HIPCHK(c, c->h_mults.reserve(total + 1));
-    HIPCHK(c, c->h_off.reserve((size_t)B + 1));
-    HIPCHK(c, c->h_nh.reserve((size_t)B));
-    HIPCHK(c, c->h_nn.reserve((size_t)B));
-    HIPCHK(c, c->h_noise.reserve((size_t)B * noise_stride));
-    if (total) std::memcpy(c->h_mults.p, mults, total * sizeof(tamcmc_multiplet));
-    std::memcpy(c->h_off.p, offsets, ((size_t)B + 1) * sizeof(int32_t));
-    std::memcpy(c->h_nh.p, nharvey, (size_t)B * sizeof(int32_t));
-    std::memcpy(c->h_nn.p, nnoise, (size_t)B * sizeof(int32_t));
-    std::memcpy(c->h_noise.p, noise, (size_t)B * noise_stride * sizeof(double));
-    return run_staged(c, B, total, noise_stride, Tcoefs, p, logL, model);
+    const StageLayout L(B, noise_stride, total);
+    HIPCHK(c, c->h_stage.reserve(L.bytes));
+    unsigned char *h = c->h_stage.p;
+    int32_t *pairs = (int32_t *)(h + L.off_pairs);
+    for (int b = 0; b < B; b++) { pairs[2 * b] = offsets[b]; pairs[2 * b + 1] = offsets[b + 1]; }
+    std::memcpy(h + L.off_nh, nharvey, (size_t)B * sizeof(int32_t));
+    std::memcpy(h + L.off_nn, nnoise, (size_t)B * sizeof(int32_t));
+    std::memcpy(h + L.off_noise, noise, (size_t)B * noise_stride * sizeof(double));
+    if (total) std::memcpy(h + L.off_mults, mults, total * sizeof(tamcmc_multiplet));
+    return run_staged(c, B, L, noise_stride, Tcoefs, p, logL, model);
 }
 
-// Build the B tables straight into the pinned staging buffers.  Vectors whose table fails keep an empty
-// table; their status is reported and their logL is forced to NaN afterwards.
+// Build the B tables straight into the pinned staging block.  Every vector owns the fixed slot
+// [b*per, (b+1)*per) of the multiplet area, so the builders are independent: host threads over parameter vectors
+// (the reference's OpenMP-over-chains axis, MALA.cpp:648, moved to the scalar unpack).  Vectors whose table fails
+// keep an empty table; their status is reported and their logL is forced to NaN afterwards.
 static int stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *params, int64_t Nparams,
-                        const int32_t *plength, int32_t *status, size_t *total_out, int *stride_out, int *first_err) {
+                        const int32_t *plength, int32_t *status, int *per_out, int *stride_out, int *first_err) {
     const int per = tamcmc::count_multiplets(model_id, plength);
     if (per < 0) return TAMCMC_ERR_BAD_MODEL;
     const int stride = plength[8] > 0 ? plength[8] : 1;
     if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
-    HIPCHK(c, c->h_mults.reserve((size_t)B * per + 1));
-    HIPCHK(c, c->h_off.reserve((size_t)B + 1));
-    HIPCHK(c, c->h_nh.reserve((size_t)B));
-    HIPCHK(c, c->h_nn.reserve((size_t)B));
-    HIPCHK(c, c->h_noise.reserve((size_t)B * stride));
-    size_t total = 0;
-    *first_err = TAMCMC_OK;
-    c->h_off.p[0] = 0;
+    const StageLayout L(B, stride, (size_t)B * per);
+    HIPCHK(c, c->h_stage.reserve(L.bytes));
+    unsigned char *h = c->h_stage.p;
+    int32_t *pairs = (int32_t *)(h + L.off_pairs), *h_nh = (int32_t *)(h + L.off_nh), *h_nn = (int32_t *)(h + L.off_nn);
+    double *h_noise = (double *)(h + L.off_noise);
+    tamcmc_multiplet *h_mults = (tamcmc_multiplet *)(h + L.off_mults);
+    const double *hx = c->hx.data();
+    const int64_t Nx = c->Nx;
+    const int nthreads = B >= 8 ? (B < 16 ? B : 16) : 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
     for (int b = 0; b < B; b++) {
         int n = 0, nh = 0, nn = 0;
-        int st = tamcmc::build_mode_table(model_id, params + (size_t)b * Nparams, plength, c->hx.data(), c->Nx,
-                                          c->h_mults.p + total, per, &n, c->h_noise.p + (size_t)b * stride, &nh, &nn);
+        int st = tamcmc::build_mode_table(model_id, params + (size_t)b * Nparams, plength, hx, Nx,
+                                          h_mults + (size_t)b * per, per, &n, h_noise + (size_t)b * stride, &nh, &nn);
         if (st == TAMCMC_OK && n > per) st = TAMCMC_ERR_BAD_ARG;
-        if (status) status[b] = st;
+        status[b] = st;
         if (st != TAMCMC_OK) {
-            if (*first_err == TAMCMC_OK) *first_err = st;
             n = 0; nh = 0; nn = 1;
-            c->h_noise.p[(size_t)b * stride] = 1.0;  // harmless placeholder row; logL[b] is overwritten with NaN
+            h_noise[(size_t)b * stride] = 1.0;  // harmless placeholder row; logL[b] is overwritten with NaN
         }
-        total += (size_t)n;
-        c->h_off.p[b + 1] = (int32_t)total;
-        c->h_nh.p[b] = nh;
-        c->h_nn.p[b] = nn;
+        pairs[2 * b] = (int32_t)((size_t)b * per);
+        pairs[2 * b + 1] = (int32_t)((size_t)b * per + n);
+        h_nh[b] = nh;
+        h_nn[b] = nn;
     }
-    *total_out = total;
+    *first_err = TAMCMC_OK;
+    for (int b = 0; b < B; b++)
+        if (status[b] != TAMCMC_OK && *first_err == TAMCMC_OK) *first_err = status[b];
+    *per_out = per;
     *stride_out = stride;
     return TAMCMC_OK;
 }
@@ -296,13 +309,12 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, cons
     if (B < 0 || !params || !plength || !logL || Nparams < 1) return TAMCMC_ERR_BAD_ARG;
     if (B == 0) return TAMCMC_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    size_t total = 0;
-    int stride = 1, first_err = TAMCMC_OK;
+    int per = 0, stride = 1, first_err = TAMCMC_OK;
     std::vector<int32_t> st_local;
     if (!status) { st_local.resize((size_t)B); status = st_local.data(); }
-    int rc = stage_params(c, model_id, B, params, Nparams, plength, status, &total, &stride, &first_err);
+    int rc = stage_params(c, model_id, B, params, Nparams, plength, status, &per, &stride, &first_err);
     if (rc) return rc;
-    rc = run_staged(c, B, total, stride, Tcoefs, p, logL, model);
+    rc = run_staged(c, B, StageLayout(B, stride, (size_t)B * per), stride, Tcoefs, p, logL, model);
     if (rc) return rc;
     for (int b = 0; b < B; b++)
         if (status[b] != TAMCMC_OK) logL[b] = NAN;

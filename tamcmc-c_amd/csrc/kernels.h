@@ -17,7 +17,7 @@ struct LoglikeArgs {
     int B;                // evaluations in this launch
     int ntiles;           // filled by launch_loglike
     const tamcmc_multiplet *mults;  // concatenated multiplet tables
-    const int32_t *offsets;         // [B+1]
+    const int32_t *offsets;         // [2B] (begin,end) multiplet range per evaluation
     const double *noise;            // [B x noise_stride] |noise params|
     int noise_stride;
     const int32_t *nharvey;         // [B]

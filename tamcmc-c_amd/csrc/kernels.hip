@@ -9,14 +9,18 @@
 //
 // Mapping: one workgroup = 256 threads = 4 wave64 = one tile of 256*K consecutive bins of ONE evaluation.
 // x/y are read coalesced (lane i -> bin base+i); the multiplets whose window intersects the tile are
-// compacted IN ORDER into LDS by wave 0 (ballot + popcount prefix) and then broadcast-read by every lane;
-// the log-likelihood terms are reduced with wave64 shuffles, then across the 4 waves through LDS.
-// No MFMA: the path is elementwise + reduction, bounded by fp64 VALU (divide) throughput, not by a contraction.
+// compacted IN ORDER into LDS by wave 0 (ballot + popcount prefix), with the per-multiplet scalars hoisted
+// (gamma^2 or 2/gamma, asymmetry constants, "covers the whole tile" / "product cannot overflow" flags), and are
+// then broadcast-read by every lane as 16-byte {nu_m, H*V_m} pairs into registers; the per-degree bodies are
+// fully unrolled (2l+1 = 1,3,5,7).  The log-likelihood terms are reduced with wave64 shuffles, then across the
+// 4 waves through LDS.  No MFMA: the path is elementwise + reduction, bounded by fp64 VALU throughput.
 // Block index -> (tile, evaluation) is XCD-aware: blocks b, b+8, b+16.. share an XCD (round-robin dispatch),
 // so all evaluations of one tile are placed on the same XCD and re-read x/y from that XCD's L2.
 //
 // Two arithmetic modes (see include/tamcmc_hip.h): STRICT keeps the reference's per-bin operation order
 // (this file is compiled with -ffp-contract=off; every fused multiply-add below is an explicit fma()).
+// FAST measured costs on MI355X (tools/ubench.hip): fma/add/mul ~1 issue slot, v_rcp_f64 ~3.3 slots with
+// 2^-24.4 relative accuracy, IEEE divide ~12.6, exp ~21, log ~72, pow ~150 slots.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,27 +33,30 @@ namespace {
 constexpr int WG = 256;
 constexpr int CHUNK = 64;  // multiplets staged per pass: one wave compacts one chunk
 
-// LDS image of a multiplet, with the per-multiplet scalars hoisted out of the per-bin loop.
-struct LdsMult {
-    int l, i0, i1, pad;
-    double fc;    // nu_c
+constexpr int F_FULL = 1;  // window covers every bin of the tile
+constexpr int F_SAFE = 2;  // FAST: product of the 2l+1 denominators stays far below DBL_MAX on this tile
+constexpr int F_ASYM = 4;  // asymmetry coefficient != 0
+
+// LDS image of a multiplet (160 B, every field group 16-byte aligned for ds_read_b128).
+struct __attribute__((aligned(16))) LdsMult {
+    int i0, i1, l, flags;
     double g;     // STRICT: gamma^2          FAST: 2/gamma
     double asym;  // asymmetry coefficient
     double c2sq;  // (0.5*gamma*asym/fc)^2
-    double afc;   // FAST: asym/fc
-    double nu[7];
-    double hv[7];
+    double fcx;   // STRICT: nu_c             FAST: asym/nu_c
+    double2 nh[7];  // {nu_nlm, H*V_m}
 };
 
-__device__ __forceinline__ double rcp_nr(double d) {
-    // v_rcp_f64 seed + two Newton-Raphson steps (explicit fma): ~1 ulp reciprocal without the
-    // div_scale/div_fmas/div_fixup sequence of an IEEE divide.
+// v_rcp_f64 seed (2^-24.4) + ONE Newton-Raphson step: relative error <= 2.1e-15
+__device__ __forceinline__ double rcp_nr1(double d) {
     double r = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    return r;
+    return fma(fma(-d, r, 1.0), r, r);
+}
+// two steps: ~1 ulp
+__device__ __forceinline__ double rcp_nr2(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
 }
 
 template <int NV>
@@ -72,6 +79,127 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double *s_red, dou
             for (int w = 1; w < WG / 64; w++) s = s + s_red[w * NV + i];
             out[i] = s;
         }
+    }
+}
+
+// ---- STRICT: the reference's statement sequence per bin, one IEEE operation per statement ----
+template <int NM, int K, bool FULL>
+__device__ __forceinline__ void strict_mult(const LdsMult &M, const double (&xv)[K], const int (&bin)[K], double (&acc)[K]) {
+    double nu[NM], hv[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        const double2 p = M.nh[m];
+        nu[m] = p.x;
+        hv[m] = p.y;
+    }
+    const double g2 = M.g;
+    const int i0 = M.i0, i1 = M.i1;
+    if (!(M.flags & F_ASYM)) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (FULL || (bin[k] >= i0 && bin[k] < i1)) {
+                double res = 0.0;
+#pragma unroll
+                for (int m = 0; m < NM; m++) {
+                    const double d = xv[k] - nu[m];
+                    double p = d * d;
+                    p = 4.0 * p / g2;
+                    const double inv = 1.0 / (1.0 + p);
+                    res = res + hv[m] * inv;
+                }
+                acc[k] = acc[k] + res;
+            }
+        }
+    } else {
+        const double asym = M.asym, fc = M.fcx, c2sq = M.c2sq;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (FULL || (bin[k] >= i0 && bin[k] < i1)) {
+                const double t = 1.0 + asym * (xv[k] / fc - 1.0);
+                const double asy = t * t + c2sq;
+                double res = 0.0;
+#pragma unroll
+                for (int m = 0; m < NM; m++) {
+                    const double d = xv[k] - nu[m];
+                    double p = d * d;
+                    p = 4.0 * p / g2;
+                    const double inv = 1.0 / (1.0 + p);
+                    res = res + hv[m] * (asy * inv);
+                }
+                acc[k] = acc[k] + res;
+            }
+        }
+    }
+}
+
+// ---- FAST: sum_m hv_m/q_m over a common denominator: 3 ops per component for q_m, 3 for (N,D),
+//      ONE reciprocal (+1 Newton step) per multiplet per bin ----
+template <int NM, int K, bool FULL>
+__device__ __forceinline__ void fast_mult(const LdsMult &M, const double (&xv)[K], const int (&bin)[K], double (&acc)[K]) {
+    double nu[NM], hv[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        const double2 p = M.nh[m];
+        nu[m] = p.x;
+        hv[m] = p.y;
+    }
+    const double g = M.g;
+    const int i0 = M.i0, i1 = M.i1;
+    const int flags = M.flags;
+    if (flags & F_SAFE) {
+        const bool has_asym = flags & F_ASYM;
+        const double afc = M.fcx, c2sq = M.c2sq, one_m_asym = 1.0 - M.asym;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (FULL || (bin[k] >= i0 && bin[k] < i1)) {
+                const double xx = xv[k];
+                double t = (xx - nu[0]) * g;
+                double D = fma(t, t, 1.0);
+                double N = hv[0];
+#pragma unroll
+                for (int m = 1; m < NM; m++) {
+                    t = (xx - nu[m]) * g;
+                    const double q = fma(t, t, 1.0);
+                    N = fma(N, q, hv[m] * D);
+                    D = D * q;
+                }
+                double res = N * rcp_nr1(D);
+                if (has_asym) {
+                    const double ta = fma(afc, xx, one_m_asym);
+                    res = res * fma(ta, ta, c2sq);
+                }
+                acc[k] = acc[k] + res;
+            }
+        }
+    } else {  // denominators too large to multiply on this tile: plain sum (never taken for sane widths)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (FULL || (bin[k] >= i0 && bin[k] < i1)) {
+                const double xx = xv[k];
+                double res = 0.0;
+#pragma unroll
+                for (int m = 0; m < NM; m++) {
+                    const double t = (xx - nu[m]) * g;
+                    res = res + hv[m] / fma(t, t, 1.0);
+                }
+                if (flags & F_ASYM) {
+                    const double ta = fma(M.fcx, xx, 1.0 - M.asym);
+                    res = res * fma(ta, ta, M.c2sq);
+                }
+                acc[k] = acc[k] + res;
+            }
+        }
+    }
+}
+
+template <bool FAST, int NM, int K>
+__device__ __forceinline__ void mult_dispatch(const LdsMult &M, const double (&xv)[K], const int (&bin)[K], double (&acc)[K]) {
+    if (M.flags & F_FULL) {
+        if (FAST) fast_mult<NM, K, true>(M, xv, bin, acc);
+        else strict_mult<NM, K, true>(M, xv, bin, acc);
+    } else {
+        if (FAST) fast_mult<NM, K, false>(M, xv, bin, acc);
+        else strict_mult<NM, K, false>(M, xv, bin, acc);
     }
 }
 
@@ -109,13 +237,10 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     const int nh = a.nharvey[b];
     const int nn = a.nnoise[b];
     if (FAST) {
-        if (tid < nh) {
-            const double tau = nz[3 * tid + 1];
-            s_lt[tid] = log(1e-3 * tau);
-        }
+        if (tid < nh) s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
     }
 
-    const int mbeg = a.offsets[b], mend = a.offsets[b + 1];
+    const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
     for (int c0 = mbeg; c0 < mend; c0 += CHUNK) {
         __syncthreads();  // previous chunk fully consumed
         if (tid < 64) {
@@ -132,14 +257,32 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 const int pos = __popcll(mask & ((1ull << tid) - 1ull));
                 const tamcmc_multiplet &g = a.mults[idx];
                 LdsMult &d = s_m[pos];
-                d.l = g.l; d.i0 = i0; d.i1 = i1; d.pad = 0;
-                d.fc = g.fc; d.asym = g.asym;
+                const int l = g.l;
+                int flags = 0;
+                if (i0 <= t0 && i1 >= t1) flags |= F_FULL;
+                if (g.asym != 0.0) flags |= F_ASYM;
                 const double c2 = 0.5 * g.gamma * g.asym / g.fc;
                 d.c2sq = c2 * c2;
-                if (FAST) { d.g = 2.0 / g.gamma; d.afc = g.asym / g.fc; }
-                else { d.g = g.gamma * g.gamma; d.afc = 0.0; }
+                d.asym = g.asym;
+                if (FAST) {
+                    const double ig = 2.0 / g.gamma;
+                    d.g = ig;
+                    d.fcx = g.asym / g.fc;
+                    // bound of prod_m (1 + ((x-nu_m) ig)^2) over the tile
+                    const double xlo = a.x[t0], xhi = a.x[t1 - 1];
+                    double lg = 0.0;
+                    for (int m = 0; m < 2 * l + 1; m++) {
+                        const double dm = fmax(fabs(xlo - g.nu[m]), fabs(xhi - g.nu[m])) * ig;
+                        lg += log2(fma(dm, dm, 1.0));
+                    }
+                    if (lg < 900.0) flags |= F_SAFE;  // also false for NaN/inf inputs
+                } else {
+                    d.g = g.gamma * g.gamma;
+                    d.fcx = g.fc;
+                }
+                d.i0 = i0; d.i1 = i1; d.l = l; d.flags = flags;
 #pragma unroll
-                for (int m = 0; m < 7; m++) { d.nu[m] = g.nu[m]; d.hv[m] = g.hv[m]; }
+                for (int m = 0; m < 7; m++) d.nh[m] = make_double2(g.nu[m], g.hv[m]);
             }
             if (tid == 0) s_n = __popcll(mask);
         }
@@ -147,63 +290,11 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
         const int n = s_n;
         for (int q = 0; q < n; q++) {
             const LdsMult &M = s_m[q];
-            const int nm = 2 * M.l + 1;
-            const int i0 = M.i0, i1 = M.i1;
-            const double asym = M.asym;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (bin[k] >= i0 && bin[k] < i1) {
-                    const double xx = xv[k];
-                    if (!FAST) {
-                        // reference operation order, one IEEE op per statement
-                        double res = 0.0;
-                        if (asym == 0.0) {
-                            for (int m = 0; m < nm; m++) {
-                                const double d = xx - M.nu[m];
-                                double p = d * d;
-                                p = 4.0 * p / M.g;
-                                const double inv = 1.0 / (1.0 + p);
-                                res = res + M.hv[m] * inv;
-                            }
-                        } else {
-                            const double t = 1.0 + asym * (xx / M.fc - 1.0);
-                            const double asy = t * t + M.c2sq;
-                            for (int m = 0; m < nm; m++) {
-                                const double d = xx - M.nu[m];
-                                double p = d * d;
-                                p = 4.0 * p / M.g;
-                                const double inv = 1.0 / (1.0 + p);
-                                res = res + M.hv[m] * (asy * inv);
-                            }
-                        }
-                        acc[k] = acc[k] + res;
-                    } else {
-                        // sum_m hv_m / q_m accumulated over a common denominator: 3 ops per component
-                        // for q_m, 3 for (N,D), ONE reciprocal per multiplet per bin.
-                        double N = 0.0, D = 1.0;
-                        for (int m = 0; m < nm; m++) {
-                            const double t = (xx - M.nu[m]) * M.g;
-                            const double qq = fma(t, t, 1.0);
-                            N = fma(N, qq, M.hv[m] * D);
-                            D = D * qq;
-                        }
-                        double res;
-                        if (D < 1e290) {
-                            res = N * rcp_nr(D);
-                        } else {  // denominators too large to multiply: plain sum (never taken for sane widths)
-                            res = 0.0;
-                            for (int m = 0; m < nm; m++) {
-                                const double t = (xx - M.nu[m]) * M.g;
-                                res = res + M.hv[m] / fma(t, t, 1.0);
-                            }
-                        }
-                        if (asym != 0.0) {
-                            const double t = fma(M.afc, xx, 1.0 - asym);
-                            res = res * fma(t, t, M.c2sq);
-                        }
-                        acc[k] = acc[k] + res;
-                    }
-                }
+            switch (M.l) {  // wave-uniform
+            case 0: mult_dispatch<FAST, 1, K>(M, xv, bin, acc); break;
+            case 1: mult_dispatch<FAST, 3, K>(M, xv, bin, acc); break;
+            case 2: mult_dispatch<FAST, 5, K>(M, xv, bin, acc); break;
+            default: mult_dispatch<FAST, 7, K>(M, xv, bin, acc); break;
             }
         }
     }
@@ -212,10 +303,13 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     // ---- background + likelihood terms ----
     double s[2] = {0.0, 0.0};
     const double white = nz[nn - 1];
+    double prod = 1.0;  // FAST: sum_k ln M_k = ln prod_k M_k (one log per K bins)
+    double Mk[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         double Mv = acc[k];
         const int bi = min(bin[k], a.Nx - 1);
+        const bool valid = bin[k] < a.Nx;
         if (!FAST) {
             for (int h = 0; h < nh; h++) {
                 const double tau = nz[3 * h + 1];
@@ -226,7 +320,7 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 }
             }
             Mv = Mv + white;
-            if (bin[k] < a.Nx) {
+            if (valid) {
                 s[0] = s[0] + a.y[bi] * (1.0 / Mv);
                 s[1] = s[1] + log(Mv);
             }
@@ -236,14 +330,26 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 const double tau = nz[3 * h + 1];
                 if (tau != 0.0) {
                     const double t = exp(nz[3 * h + 2] * (s_lt[h] + lx));
-                    Mv = fma(nz[3 * h], rcp_nr(t + 1.0), Mv);
+                    Mv = fma(nz[3 * h], rcp_nr2(t + 1.0), Mv);
                 }
             }
             Mv = Mv + white;
-            if (bin[k] < a.Nx) s[0] = s[0] + fma(a.y[bi], rcp_nr(Mv), log(Mv));
+            if (valid) {
+                s[0] = fma(a.y[bi], rcp_nr2(Mv), s[0]);
+                prod = prod * Mv;
+            }
         }
+        Mk[k] = Mv;
         if (WRITE_MODEL) {
-            if (bin[k] < a.Nx) a.model[(size_t)b * a.Nx + bin[k]] = Mv;
+            if (valid) a.model[(size_t)b * a.Nx + bin[k]] = Mv;
+        }
+    }
+    if (FAST) {
+        if (prod > 1e-280 && prod < 1e280) s[1] = log(prod);
+        else {  // product out of range (or NaN): the plain sum of logs
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (bin[k] < a.Nx) s[1] = s[1] + log(Mk[k]);
         }
     }
     __syncthreads();

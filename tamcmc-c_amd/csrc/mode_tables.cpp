@@ -37,7 +37,7 @@ static long double ritzwoller_H(int s, int l, int m) {
     return H;
 }
 
-long double Pslm(int s, int l, int m) {
+static long double Pslm_compute(int s, int l, int m) {
     const double dm = m, dl = l;
     long double Ps = 0;
     if (s == 1) Ps = m;
@@ -70,11 +70,40 @@ long double Pslm(int s, int l, int m) {
 }
 
 // build_lorentzian.cpp:583-592
-double Qlm(int l, int m) {
+static double Qlm_compute(int l, int m) {
     const long double Dnl = 2. / 3;
     double q = (l * (l + 1) - 3 * std::pow((double)m, 2)) / ((2 * l - 1) * (2 * l + 3));
     q = q * Dnl;
     return q;
+}
+
+// The polynomials depend on (s,l,m) only: evaluate them once (s<=6, l<=3, |m|<=3) and serve every later call from
+// the table -- same values, bit for bit, as recomputing them per multiplet like the reference does.
+namespace {
+struct PolyTables {
+    long double P[7][4][7];
+    double Q[4][7];
+    PolyTables() {
+        for (int s = 0; s <= 6; s++)
+            for (int l = 0; l <= 3; l++)
+                for (int m = -3; m <= 3; m++) P[s][l][m + 3] = Pslm_compute(s, l, m);
+        for (int l = 0; l <= 3; l++)
+            for (int m = -3; m <= 3; m++) Q[l][m + 3] = Qlm_compute(l, m);
+    }
+};
+const PolyTables &poly() {
+    static const PolyTables t;
+    return t;
+}
+}  // namespace
+
+long double Pslm(int s, int l, int m) {
+    if (s >= 0 && s <= 6 && l >= 0 && l <= 3 && m >= -3 && m <= 3) return poly().P[s][l][m + 3];
+    return Pslm_compute(s, l, m);
+}
+double Qlm(int l, int m) {
+    if (l >= 0 && l <= 3 && m >= -3 && m <= 3) return poly().Q[l][m + 3];
+    return Qlm_compute(l, m);
 }
 
 // ---------- m-visibilities: function_rot.cpp:15-101 ----------

@@ -1,6 +1,6 @@
 """GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs.  Tolerances (fp64):
-  STRICT model row : bit-exact when the Harvey pow() terms are inactive; <= 4e-16 relative otherwise (device pow vs libm)
+  STRICT model row : bit-exact when the Harvey pow() terms are inactive; <= 1e-15 relative otherwise (device pow vs libm)
   FAST   model row : <= 1e-12 relative per bin
   logL             : <= 1e-12 (STRICT) / 1e-11 (FAST) relative against the 80-bit-accumulated oracle sum;
                      the reference's own acceptance bound ||dM||_2 <= 1e-8 (test_build_l_mode.cpp:104,134) is the envelope.
@@ -93,7 +93,7 @@ def test_c3_like_global_with_harvey_and_asymmetry(pkg, oracle, synth, ctxs):
     T = 1.4 ** np.arange(B)
     ref, m_o, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T, want_model=True)
     assert (st_o == 0).all()
-    for name, tol_m, tol_l in (("strict", 4e-16, 1e-12), ("fast", 1e-12, 1e-11)):
+    for name, tol_m, tol_l in (("strict", 1e-15, 1e-12), ("fast", 1e-12, 1e-11)):
         c = ctxs[name]
         c.set_spectrum(star.x, y)
         logL, model, status = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0, want_model=True)
