@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--precision", choices=["fast", "strict"], default="fast")
     ap.add_argument("--sampler", choices=["mh", "mala"], default="mh",
                     help="mh = adaptive random-walk MH + PT (what the reference runs); mala = Langevin drift, FD gradient")
+    ap.add_argument("--engine", choices=["device", "host"], default="device",
+                    help="device = whole MCMC iteration resident on the GPU; host = host-driven loop (one device call per step)")
     ap.add_argument("--mala-steps", type=int, default=30, help="extra MALA-FD measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,7 +101,8 @@ def main():
     ctx.set_spectrum(star.x, y)
 
     def make_sampler(use_drift, learn_until):
-        return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank,
+        eng = "host" if use_drift else a.engine   # the Langevin drift runs on the host-driven engine
+        return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=eng,
                            Nt_learn=(max(learn_until // 2, 1), max(learn_until, 2)), periods_learn=(1,), dN_mixing=1)
 
     def barrier():
@@ -157,6 +160,8 @@ def main():
                                    f"{len(mults)} multiplets, {a.chains} tempered chains (lambda={lam}), one star per GPU",
                        "sampler": "adaptive random-walk MH + parallel tempering (use_drift=0, the reference's sampler)"
                        if a.sampler == "mh" else "Langevin drift, forward-difference gradient (use_drift=1)",
+                       "engine": ("device-resident iteration (propose/prior/unpack/accept/swap kernels, no host round trip)"
+                                  if (a.engine == "device" and a.sampler == "mh") else "host-driven loop"),
                        "arithmetic": a.precision, "component_bin_evals_per_model": W},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_loglike",

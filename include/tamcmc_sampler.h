@@ -42,7 +42,9 @@ typedef struct tamcmc_sampler_config {
     const int64_t *Nt_learn;       /* [n_Nt_learn] */
     const int64_t *periods_learn;  /* [n_Nt_learn-1] */
     int32_t n_Nt_learn;
-    int32_t reserved0;
+    int32_t engine;                /* 0 = host-driven loop (one batched device call per iteration),
+                                      1 = device-resident iteration (proposal, priors, unpack, accept, swap, adaptation on the GPU;
+                                          use_drift must be 0) */
     int64_t dN_mixing;
     const double *init_errors;     /* [Nvars] initial proposal standard deviations (errors_default.cfg), NULL -> 1 */
     /* additions of this build */

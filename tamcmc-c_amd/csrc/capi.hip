@@ -14,98 +14,9 @@
 #include "kernels.h"
 #include "mode_tables.h"
 
-namespace {
+#include "ctx.h"
 
-template <typename T>
-struct DevBuf {  // grow-only device buffer
-    T *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 2 + 64;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-template <typename T>
-struct PinBuf {  // grow-only pinned host buffer
-    T *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 2 + 64;
-        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-}  // namespace
-
-struct tamcmc_hip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string err;
-    // options
-    int precision = TAMCMC_PRECISION_STRICT;
-    int timing = 0;
-    int K = 2;
-    // resident spectrum
-    int64_t Nx = 0;
-    std::vector<double> hx;  // host copy of x (table builders need x[0], x[Nx-1], step)
-    DevBuf<double> dx, dy, dlogx;
-    // ONE pinned staging block and its device image per call (a single H2D copy):
-    //   [int32 begin/end pairs 2B | int32 nharvey B | int32 nnoise B | pad] [double noise B*stride] [multiplets]
-    PinBuf<unsigned char> h_stage;
-    DevBuf<unsigned char> d_stage;
-    DevBuf<double> d_part, d_S, d_model;
-    PinBuf<double> h_S;
-    // stats
-    double kernel_ms = 0;
-    int64_t launches = 0, evals = 0;
-};
-
-namespace {
-struct StageLayout {
-    size_t off_pairs, off_nh, off_nn, off_noise, off_mults, bytes;
-    StageLayout(int B, int stride, size_t total_mults) {
-        off_pairs = 0;
-        off_nh = off_pairs + (size_t)2 * B * sizeof(int32_t);
-        off_nn = off_nh + (size_t)B * sizeof(int32_t);
-        off_noise = (off_nn + (size_t)B * sizeof(int32_t) + 15) & ~(size_t)15;
-        off_mults = (off_noise + (size_t)B * stride * sizeof(double) + 15) & ~(size_t)15;
-        bytes = off_mults + (total_mults + 1) * sizeof(tamcmc_multiplet);
-    }
-};
-}  // namespace
-
-#define HIPCHK(ctx, call)                                                                     \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
-            return TAMCMC_ERR_HIP;                                                            \
-        }                                                                                     \
-    } while (0)
+using tamcmc::StageLayout;
 
 extern "C" {
 

@@ -1,0 +1,68 @@
+// dev_sampler.h -- interface of the device-resident sampler engine (dev_sampler.hip).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/tamcmc_hip.h"
+
+#define TAMCMC_MAX_CHAINS 64  // the reference caps at 24 (MALA.cpp:580-587); BASELINE config 5 asks for 40
+
+namespace tamcmc {
+
+// Kernel argument block: device pointers + scalars (passed by value).
+struct DevSamplerArgs {
+    int model_id, prior_class, C, Np, Nv, per, stride, Nx, ntiles, chol_in_lds;
+    long pl;              // likelihood_params truncated to long (likelihoods.h:14)
+    long dN_mixing;
+    uint64_t seed;
+    double x_first, x_last, step;
+    double c0, epsilon1, epsi2, A1, target_acceptance;
+    // model description (constant)
+    const int *plength, *index_to_relax, *priors_switch;
+    const double *priors, *extra, *Tcoefs;
+    // chain state
+    double *vars_cur, *params_cur, *logL_cur, *logPr_cur, *logPost_cur, *init_logL;
+    double *vars_prop, *params_prop, *logPr_prop;
+    int *status_prop, *moved;
+    double *Pmove;
+    long *counters;       // [0] iteration, [1] accepted moves of chain 0, [2] swap attempts, [3] swaps accepted
+    // proposal law
+    double *LT, *cov, *mu, *sigma;   // LT = transposed Cholesky factor of (cov+eps2)*sigma
+    // likelihood-kernel input block written by k_propose_unpack
+    tamcmc_multiplet *mults;
+    int *pairs, *nh, *nn;
+    double *noise;
+    double *partials;
+    // records
+    double *samples, *stats;
+};
+
+struct DevSamplerInit {
+    int model_id, prior_class, C, Np, Nv;
+    double likelihood_params;
+    const int *plength, *index_to_relax, *priors_switch;
+    const double *priors, *extra_priors, *Tcoefs;
+    uint64_t seed;
+    long dN_mixing;
+    double c0, epsilon1, epsi2, A1, target_acceptance;
+};
+
+class DevSampler {
+    struct Impl;
+    Impl *impl;
+
+  public:
+    DevSampler();
+    ~DevSampler();
+    DevSampler(const DevSampler &) = delete;
+    DevSampler &operator=(const DevSampler &) = delete;
+    int init(tamcmc_hip_ctx *ctx, const DevSamplerInit &in);
+    int upload_state(const double *vars, const double *params, const double *logL, const double *logPr,
+                     const double *logPost, const double *init_logL);
+    int upload_proposal(int m, const double *L_rowmajor, const double *cov, const double *mu, double sigma);
+    int download_state(double *vars, double *params, double *logL, double *logPr, double *logPost, double *Pmove,
+                       int *moved, long *counters);
+    int download_proposal(int m, double *cov, double *mu, double *sigma);
+    int run(long it0, long n_iter, const char *learn, double *samples, double *stats);
+};
+
+}  // namespace tamcmc

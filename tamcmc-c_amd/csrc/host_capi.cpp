@@ -4,6 +4,7 @@
 #include <string>
 
 #include "../../include/tamcmc_sampler.h"
+#include "dev_sampler.h"
 #include "host_sampler.h"
 
 using namespace tamcmc;
@@ -12,8 +13,31 @@ struct tamcmc_sampler {
     Config cfg;
     std::unique_ptr<MALA> mala;
     std::unique_ptr<Model_def> cur, prop;
+    std::unique_ptr<DevSampler> dev;  // engine 1: the iteration runs on the GPU, the host objects mirror its state
     long accepted0 = 0;
+    int sync_from_device(bool proposal_too);
 };
+
+// pull the device engine's chain state (and, after learning, its proposal law) into the host mirrors
+int tamcmc_sampler::sync_from_device(bool proposal_too) {
+    const long Nc = cfg.MALA.Nchains;
+    std::vector<int> moved((size_t)Nc);
+    long counters[4];
+    int rc = dev->download_state(cur->vars.a.data(), cur->params.a.data(), cur->logLikelihood.data(), cur->logPrior.data(),
+                                 cur->logPosterior.data(), cur->Pmove.data(), moved.data(), counters);
+    if (rc) return rc;
+    for (long m = 0; m < Nc; m++) cur->moved[(size_t)m] = (char)moved[(size_t)m];
+    accepted0 = counters[1];
+    mala->Nswap_attempts = counters[2];
+    mala->Nswap_accepted = counters[3];
+    if (proposal_too)
+        for (long m = 0; m < Nc; m++) {
+            rc = dev->download_proposal((int)m, mala->covarmat[(size_t)m].a.data(), mala->mu.row(m), &mala->sigma[(size_t)m]);
+            if (rc) return rc;
+            mala->invalidate((int)m);
+        }
+    return TAMCMC_OK;
+}
 
 extern "C" {
 
@@ -70,6 +94,28 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
     s->cur = std::make_unique<Model_def>(&g, s->mala->Tcoefs, false, ctx);
     if (s->cur->last_status != TAMCMC_OK) return s->cur->last_status;
     s->prop = std::make_unique<Model_def>(*s->cur);
+    if (c->engine == 1) {
+        if (c->use_drift != 0) return TAMCMC_ERR_BAD_ARG;  // the Langevin drift runs on the host-driven engine
+        s->dev = std::make_unique<DevSampler>();
+        std::vector<int> idx(s->cur->get_index_to_relax());
+        DevSamplerInit di;
+        di.model_id = c->model_id; di.prior_class = c->prior_class; di.C = c->Nchains; di.Np = (int)c->Nparams; di.Nv = (int)nv;
+        di.likelihood_params = c->likelihood_params;
+        di.plength = in.plength.data(); di.index_to_relax = idx.data(); di.priors_switch = in.priors_names_switch.data();
+        di.priors = in.priors.a.data(); di.extra_priors = in.extra_priors.data(); di.Tcoefs = s->mala->Tcoefs.data();
+        di.seed = c->seed; di.dN_mixing = (long)c->dN_mixing;
+        di.c0 = c->c0; di.epsilon1 = c->epsilon1; di.epsi2 = c->epsilon2; di.A1 = c->A1; di.target_acceptance = c->target_acceptance;
+        int rc = s->dev->init(ctx, di);
+        if (rc) return rc;
+        rc = s->dev->upload_state(s->cur->vars.a.data(), s->cur->params.a.data(), s->cur->logLikelihood.data(),
+                                  s->cur->logPrior.data(), s->cur->logPosterior.data(), s->cur->init_logLikelihood.data());
+        if (rc) return rc;
+        for (int m = 0; m < c->Nchains; m++) {
+            rc = s->dev->upload_proposal(m, s->mala->factor(m).a.data(), s->mala->covarmat[(size_t)m].a.data(), s->mala->mu.row(m),
+                                         s->mala->sigma[(size_t)m]);
+            if (rc) return rc;
+        }
+    }
     *out = s.release();
     return TAMCMC_OK;
 }
@@ -81,6 +127,16 @@ int64_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->cur->get_N
 int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, double *stats) {
     if (!s || n_iter < 0) return TAMCMC_ERR_BAD_ARG;
     const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    if (s->dev) {
+        const long it0 = s->mala->iteration;
+        std::vector<char> learn((size_t)n_iter);
+        bool any = false;
+        for (int64_t i = 0; i < n_iter; i++) { learn[(size_t)i] = s->mala->learn_at(it0 + i) ? 1 : 0; any = any || learn[(size_t)i]; }
+        int rc = s->dev->run(it0, (long)n_iter, any ? learn.data() : nullptr, samples, stats);
+        if (rc) return rc;
+        s->mala->iteration = it0 + (long)n_iter;
+        return s->sync_from_device(any);
+    }
     for (int64_t it = 0; it < n_iter; it++) {
         int rc = s->mala->step(s->cur.get(), s->prop.get(), &s->cfg.data.data, &s->cfg);
         if (rc) return rc;
@@ -131,6 +187,9 @@ int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, 
     if (covarmat) std::memcpy(s->mala->covarmat[(size_t)m].a.data(), covarmat, (size_t)(Nv * Nv) * sizeof(double));
     if (sigma > 0) s->mala->sigma[(size_t)m] = sigma;
     s->mala->invalidate(m);
+    if (s->dev)
+        return s->dev->upload_proposal(m, s->mala->factor(m).a.data(), s->mala->covarmat[(size_t)m].a.data(), s->mala->mu.row(m),
+                                       s->mala->sigma[(size_t)m]);
     return TAMCMC_OK;
 }
 

@@ -286,6 +286,14 @@ int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const st
     return rc;
 }
 
+bool MALA::learn_at(long i) const {
+    bool logic = false;
+    long which = 0;
+    for (size_t l = 0; l < periods_learn.size() && l + 1 < Nt_learn.size(); l++)
+        if ((i >= Nt_learn[l]) && (i < Nt_learn[l + 1])) { logic = true; which = (long)l; }
+    return logic && (i % periods_learn[(size_t)which]) == 0;
+}
+
 // One iteration i of MALA::execute's loop body (MALA.cpp:645-703) for all chains.
 int MALA::step(Model_def *cur, Model_def *prop, Data *data, Config *) {
     const long i = iteration;
@@ -356,11 +364,7 @@ int MALA::step(Model_def *cur, Model_def *prop, Data *data, Config *) {
         cur->Pmove[(size_t)m] = (double)r;
         cur->comparator_MH[(size_t)m] = u;
         // [2'] learning (MALA.cpp:656-667)
-        bool logic = false;
-        long which = 0;
-        for (size_t l = 0; l < periods_learn.size() && l + 1 < Nt_learn.size(); l++)
-            if ((i >= Nt_learn[l]) && (i < Nt_learn[l + 1])) { logic = true; which = (long)l; }
-        if (logic && (i % periods_learn[(size_t)which]) == 0)
+        if (learn_at(i))
             update_proposal(cur->vars.row(m), cur->Pmove[(size_t)m], (int)m);  // position unchanged: gradient stays valid
     }
     // [3] parallel tempering (MALA.cpp:688-703)

@@ -165,6 +165,8 @@ class MALA {  // MALA.h:26-69
     int step(Model_def *model_current, Model_def *model_propose, Data *data_struc, Config *cfg);
     int compute_gradients(Model_def *model, Data *data_struc, Matrix &grad_out, const std::vector<char> &which);
     const Matrix &factor(int m);
+    bool learn_at(long i) const;  // MALA.cpp:656-667: is the proposal law updated after iteration i?
+    uint64_t get_seed() const { return seed; }
     void invalidate(int m) { Lchol_valid[(size_t)m] = 0; grad_valid[(size_t)m] = 0; }
 };
 

@@ -16,7 +16,7 @@ class SamplerConfig(C.Structure):
                 ("Nchains", C.c_int32), ("lambda_temp", C.c_double), ("target_acceptance", C.c_double), ("c0", C.c_double),
                 ("epsilon1", C.c_double), ("epsilon2", C.c_double), ("A1", C.c_double), ("delta", C.c_double),
                 ("delta_x", C.c_double), ("Nt_learn", _i64p), ("periods_learn", _i64p), ("n_Nt_learn", C.c_int32),
-                ("reserved0", C.c_int32), ("dN_mixing", C.c_int64), ("init_errors", _dp), ("seed", C.c_uint64),
+                ("engine", C.c_int32), ("dN_mixing", C.c_int64), ("init_errors", _dp), ("seed", C.c_uint64),
                 ("fd_step_rel", C.c_double)]
 
 
@@ -47,7 +47,8 @@ class Sampler:
 
     def __init__(self, ctx: HipContext, star, nchains=5, lambda_temp=3.5, use_drift=0, seed=20240229, p=1.0,
                  target_acceptance=0.234, c0=10.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, delta=0.0, delta_x=1e-10,
-                 Nt_learn=(1000, 1500, 100000), periods_learn=(1, 1), dN_mixing=1, init_errors=None, fd_step_rel=1e-7):
+                 Nt_learn=(1000, 1500, 100000), periods_learn=(1, 1), dN_mixing=1, init_errors=None, fd_step_rel=1e-7,
+                 engine="host"):
         self._L = _rebind()
         self.ctx = ctx
         self.nchains = int(nchains)
@@ -75,6 +76,7 @@ class Sampler:
         cfg.epsilon1, cfg.epsilon2, cfg.A1, cfg.delta, cfg.delta_x = epsilon1, epsilon2, A1, delta, delta_x
         cfg.Nt_learn, cfg.periods_learn, cfg.n_Nt_learn = _p(keep["Nt"], _i64p), _p(keep["per"], _i64p), keep["Nt"].size
         cfg.dN_mixing, cfg.init_errors, cfg.seed, cfg.fd_step_rel = int(dN_mixing), _p(keep["err"]), int(seed), fd_step_rel
+        cfg.engine = {"host": 0, "device": 1}[engine]
         h = _vp()
         st = self._L.tamcmc_sampler_create(C.byref(h), ctx._h, C.byref(cfg))
         if st != OK:
