@@ -19,6 +19,7 @@ struct DevSamplerArgs {
     // model description (constant)
     const int *plength, *index_to_relax, *priors_switch;
     const double *priors, *extra, *Tcoefs;
+    const void *poly;     // mt::PolyTab (Pslm/Qlm tables) in device memory
     // chain state
     double *vars_cur, *params_cur, *logL_cur, *logPr_cur, *logPost_cur, *init_logL;
     double *vars_prop, *params_prop, *logPr_prop;

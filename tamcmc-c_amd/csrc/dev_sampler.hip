@@ -30,8 +30,6 @@ namespace tamcmc {
 
 namespace {
 
-__device__ __constant__ mt::PolyTab c_poly;  // Pslm/Qlm tables (double on the device)
-
 __global__ void k_fill_poly(mt::PolyTab *t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) mt::fill_poly(*t);
 }
@@ -149,7 +147,7 @@ __global__ void __launch_bounds__(PB) k_propose_unpack(const DevSamplerArgs a, c
         __syncthreads();
         for (int idx = tid; idx < per; idx += PB) {
             tamcmc_multiplet r;
-            const int st = mt::build_multiplet(a.model_id, c_poly, s_params, *S, idx, a.x_first, a.x_last, a.Nx, a.step, &r);
+            const int st = mt::build_multiplet(a.model_id, *(const mt::PolyTab *)a.poly, s_params, *S, idx, a.x_first, a.x_last, a.Nx, a.step, &r);
             if (st) s_status = st;
             else a.mults[(size_t)m * per + idx] = r;
         }
@@ -464,12 +462,12 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     I.lds_propose = (Np + 2 * Nv + 1 + 4) * sizeof(double) + sizeof(mt::Shared) + 64;
     if (I.lds_adapt > 64 * 1024)
         DCHK(hipFuncSetAttribute((const void *)k_adapt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_adapt));
-    // polynomial tables: computed ON the device (double arithmetic) into a scratch, then into constant memory
+    // polynomial tables Pslm/Qlm: computed ON the device (its own double arithmetic), read through a uniform pointer
     mt::PolyTab *d_tab;
     DCHK(I.dalloc(&d_tab, 1));
     hipLaunchKernelGGL(k_fill_poly, dim3(1), dim3(64), 0, st, d_tab);
     DCHK(hipGetLastError());
-    DCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_poly), d_tab, sizeof(mt::PolyTab), 0, hipMemcpyDeviceToDevice, st));
+    a.poly = d_tab;
     for (int i = 0; i < 64; i++) { DCHK(hipEventCreate(&I.ev[i][0])); DCHK(hipEventCreate(&I.ev[i][1])); I.n_ev = i + 1; }
     DCHK(hipStreamSynchronize(st));
     return TAMCMC_OK;
