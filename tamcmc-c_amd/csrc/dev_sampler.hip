@@ -1,17 +1,21 @@
 // dev_sampler.hip -- device-resident MCMC iteration (sampler-side algebra on the device).
 //
 // The host-driven loop (host_mala.cpp) spends ~3/4 of a step on the host (proposal, priors, table build, copies,
-// one sync per step).  Here one MCMC iteration of ALL tempered chains is three kernels on the context's stream,
-// with no host round trip and no copy in between:
-//   k_propose_unpack  (one workgroup per chain)  z ~ N(0,I) (Philox, same streams as the host engine),
-//                     x' = x + L z, params', log-prior (terms in parallel), params' -> multiplet table + noise row
-//                     written straight into the likelihood kernel's input block
-//                     (MALA.cpp:339-369 new_prop_values, model_def.cpp:484-492, priors_calc.cpp, models.cpp unpackers)
-//   k_loglike         (kernels.hip)               the hot kernel, unchanged
-//   k_accept_swap     (one workgroup)             per-chain partial sums -> tempered logL, MH accept (MALA.cpp:490-551),
-//                     adjacent-pair parallel-tempering swap (MALA.cpp:397-461), sample/stat record (outputs.cpp buffers)
-//   k_adapt           (one workgroup per chain, learning phases only) Robbins-Monro update of mu, Sigma, sigma
-//                     (MALA.cpp:296-319) and Cholesky of (Sigma+eps2 I) sigma (MALA.cpp:348-350)
+// one sync per step).  Here one MCMC iteration of ALL tempered chains is TWO kernels on the context's stream, with no
+// host round trip and no copy in between:
+//   k_iterate  (one workgroup per chain)
+//      (0) settles the previous iteration: per-chain partial sums -> tempered logL, MH test (MALA.cpp:490-551),
+//          adjacent-pair parallel-tempering swap (MALA.cpp:397-461), sample/stat record (the outputs.cpp buffers),
+//          in learning phases the Robbins-Monro update of mu, Sigma, sigma (MALA.cpp:296-319) and the Cholesky
+//          factor of (Sigma+eps2 I) sigma (MALA.cpp:348-350);
+//      (1) proposes the next one: z ~ N(0,I) (Philox, same streams as the host engine), x' = x + L z
+//          (MALA.cpp:339-369), params' (model_def.cpp:484-492), log-prior with its terms spread over the lanes
+//          (priors_calc.cpp), params' -> multiplet table + noise row (models.cpp unpackers) written straight into
+//          the likelihood kernel's input block.
+//   k_loglike  (kernels.hip)  the hot kernel, unchanged.
+// All per-iteration state is double-buffered by parity: a workgroup reads parity P (any chain) and writes parity P^1
+// (its own chain only), so the swap needs no inter-workgroup synchronisation: the two workgroups of a swap pair
+// both recompute both MH tests from the same inputs and reach the same decision.
 // The host only enqueues launches and fetches the recorded samples once per run() call.
 #include <hip/hip_runtime.h>
 
@@ -34,7 +38,7 @@ __global__ void k_fill_poly(mt::PolyTab *t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) mt::fill_poly(*t);
 }
 
-constexpr int PB = 128;  // threads of k_propose_unpack
+constexpr int TB = 256;  // threads of k_iterate (one workgroup per chain)
 
 __device__ __forceinline__ double block_sum(double v, double *s_red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -45,264 +49,78 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
     __syncthreads();
     double s = s_red[0];
     for (int w = 1; w < nw; w++) s = s + s_red[w];
+    __syncthreads();
     return s;
 }
 
-__global__ void __launch_bounds__(PB) k_propose_unpack(const DevSamplerArgs a, const long it) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    double *s_params = (double *)s_raw;          // [Np]
-    double *s_vars = s_params + a.Np;            // [Nv]
-    double *s_z = s_vars + a.Nv;                 // [Nv + 1]
-    double *s_red = s_z + a.Nv + 1;              // [4]
-    mt::Shared *S = (mt::Shared *)(s_red + 4);   // shared scalars of the unpack
-    __shared__ int s_status;
-    __shared__ double s_c, s_dnu;
+// Outcome of the Metropolis-Hastings test of chain j for the pending iteration (MALA.cpp:490-551): the values the
+// chain holds AFTER the test.  Computed by a whole workgroup; every workgroup that needs chain j's outcome (the chain's
+// own workgroup and, in a swap step, its partner's) recomputes it from the same inputs -> identical results.
+struct AcceptOut {
+    int acc;
+    double r, logL, logPr, logPost;
+};
 
-    const int m = blockIdx.x, tid = threadIdx.x;
-    const int Np = a.Np, Nv = a.Nv;
-    // ---- proposal: x' = x + L z (MALA.cpp:348-355), L = chol((Sigma+eps2) sigma), stored transposed ----
-    for (int k2 = tid; 2 * k2 < Nv; k2 += PB) {
-        double z0, z1;
-        rng_normal2(a.seed, RNG_PROPOSAL, (uint32_t)m, (uint64_t)it, (uint32_t)k2, z0, z1);
-        s_z[2 * k2] = z0;
-        s_z[2 * k2 + 1] = z1;
+__device__ void accept_result(const DevSamplerArgs &a, int j, long itp, int P, double *s_red, AcceptOut *s_out) {
+    const int tid = threadIdx.x;
+    // same reduction order as k_finalize (kernels.hip): strided per-thread sums, shuffle tree, waves in order
+    double s1 = 0, s2 = 0;
+    for (int t = tid; t < a.ntiles; t += TB) {
+        const double *p = a.partials + ((size_t)j * a.ntiles + t) * 2;
+        s1 = s1 + p[0];
+        s2 = s2 + p[1];
     }
-    for (int i = tid; i < Np; i += PB) s_params[i] = a.params_cur[(size_t)m * Np + i];
-    if (tid == 0) s_status = TAMCMC_OK;
-    __syncthreads();
-    const double *LT = a.LT + (size_t)m * Nv * Nv;
-    for (int i = tid; i < Nv; i += PB) {
-        double s = 0;
-        for (int k = 0; k <= i; k++) s = s + LT[(size_t)k * Nv + i] * s_z[k];
-        const double v = a.vars_cur[(size_t)m * Nv + i] + 0.0 + s;
-        s_vars[i] = v;
-        a.vars_prop[(size_t)m * Nv + i] = v;
-    }
-    __syncthreads();
-    for (int k = tid; k < Nv; k += PB) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
-    __syncthreads();
-    for (int i = tid; i < Np; i += PB) a.params_prop[(size_t)m * Np + i] = s_params[i];
-
-    // ---- log-prior: hard constraints by one lane, additive terms one per lane, tree-summed ----
-    if (tid == 0) {
-        int st = TAMCMC_OK;
-        mt::xreal c;
-        if (a.prior_class == 2) {
-            c = pr::ms_global_constraints(s_params, a.plength, a.priors_switch, a.extra, &st);
-            double fit[2];
-            mt::linfit_index(s_params + a.plength[0] + a.plength[1], a.plength[2], fit);
-            s_dnu = fit[0];
-        } else if (a.prior_class == 3) {
-            c = pr::local_constraints(s_params, a.plength, a.priors_switch, a.extra);
-        } else {
-            c = pr::neg_inf();
-            st = TAMCMC_ERR_BAD_MODEL;
-        }
-        s_c = c;
-        if (st != TAMCMC_OK) s_status = st;
-    }
-    __syncthreads();
-    double logPr;
-    {
-        const int n_extra = (a.prior_class == 2) ? pr::ms_global_extra_terms(a.plength, a.extra) : 0;
-        double f = 0;
-        int st = TAMCMC_OK;
-        for (int t = tid; t < Np + n_extra; t += PB) {
-            if (t < Np) f = f + pr::generic_prior_term(s_params, Np, a.priors, a.priors_switch, t, &st);
-            else f = f + pr::ms_global_extra_term(s_params, a.plength, a.extra, s_dnu, t - Np);
-        }
-        if (st != TAMCMC_OK) s_status = st;
-        f = block_sum(f, s_red);
-        logPr = (s_c != 0) ? s_c : f;
-    }
-
-    // ---- params' -> multiplet table (skipped when the prior is -inf: model_def.cpp:472,476-480) ----
-    const int per = a.per;
-    const bool live = (logPr != -INFINITY) && !isnan(logPr);
-    if (live) {
-        if (tid == 0) {
-            mt::shared_scalars_base(a.model_id, s_params, a.plength, *S);
-        }
-        __syncthreads();
-        // m-visibilities: one lane per Wigner element d^l_{i,0}, i=0..l, l=1..3 (9 lanes) + the centre elements
-        if (tid < 12) {
-            int l, i;
-            if (tid < 2) { l = 1; i = tid; } else if (tid < 5) { l = 2; i = tid - 2; } else if (tid < 9) { l = 3; i = tid - 5; }
-            else { l = tid - 8; i = -1; }
-            if (S->need_ratio[l]) {
-                const double PI = 3.141592653589793238462643;
-                const double ang = PI * S->inc / 180.;
-                if (i >= 0) S->ratios[l][l + i] = mt::wigner_d(l, i, 0, ang);
-                else S->centre[l] = mt::wigner_d(l, 0, 0, -ang);
-            }
-        }
-        __syncthreads();
-        if (tid >= 1 && tid <= 3 && S->need_ratio[tid]) {  // mirror, centre overwrite, square (function_rot.cpp:25-41)
-            const int l = tid;
-            double *V = S->ratios[l];
-            for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * pow(-1.0, (double)i);
-            V[l] = S->centre[l] * pow(-1.0, 0.);
-            for (int i = 0; i <= 2 * l; i++) V[i] = V[i] * V[i];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < per; idx += PB) {
-            tamcmc_multiplet r;
-            const int st = mt::build_multiplet(a.model_id, *(const mt::PolyTab *)a.poly, s_params, *S, idx, a.x_first, a.x_last, a.Nx, a.step, &r);
-            if (st) s_status = st;
-            else a.mults[(size_t)m * per + idx] = r;
-        }
-        for (int i = tid; i < S->L.Nnoise; i += PB) a.noise[(size_t)m * a.stride + i] = fabs(s_params[S->L.o_noise + i]);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const bool ok = live && (s_status == TAMCMC_OK);
-        a.pairs[2 * m] = m * per;
-        a.pairs[2 * m + 1] = ok ? (m + 1) * per : m * per;
-        a.nh[m] = ok ? S->nharvey : 0;
-        a.nn[m] = ok ? S->L.Nnoise : 1;
-        if (!ok) a.noise[(size_t)m * a.stride] = 1.0;  // placeholder row; the chain is rejected in k_accept_swap
-        a.logPr_prop[m] = logPr;
-        a.status_prop[m] = s_status;
-    }
-}
-
-// One workgroup: finalize + accept + swap + record for every chain.
-__global__ void __launch_bounds__(256) k_accept_swap(const DevSamplerArgs a, const long it, const long rec) {
-    __shared__ int s_acc[TAMCMC_MAX_CHAINS];
-    __shared__ int s_swapA;
-    __shared__ double s_swapvals[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = a.C, Nv = a.Nv, Np = a.Np;
-    // ---- per chain: partial sums -> tempered logL; Metropolis-Hastings test (MALA.cpp:490-551) ----
-    for (int m = wave; m < C; m += 4) {
-        double s1 = 0, s2 = 0;
-        for (int t = lane; t < a.ntiles; t += 64) {
-            const double *p = a.partials + ((size_t)m * a.ntiles + t) * 2;
-            s1 = s1 + p[0];
-            s2 = s2 + p[1];
-        }
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            s1 = s1 + __shfl_down(s1, off, 64);
-            s2 = s2 + __shfl_down(s2, off, 64);
-        }
-        if (lane == 0) {
-            const double S = s1 + s2;
-            double logL = (-(double)a.pl * S) / a.Tcoefs[m];  // call_likelihood, model_def.cpp:399-401
-            const double logPr = a.logPr_prop[m];
-            double logPost;
-            if (a.status_prop[m] != TAMCMC_OK) logL = NAN;
-            if (logPr == -INFINITY || isnan(logPr)) { logL = a.init_logL[m]; logPost = -INFINITY; }
-            else logPost = logL + logPr;
-            double u, u1;
-            rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)m, (uint64_t)it, 0, u, u1);
-            double r;
-            if (!isnan(logL)) {
-                if (logPost == -INFINITY) r = 0.;
-                else {
-                    const double e = exp(logPost - a.logPost_cur[m]);
-                    r = fmin(1.0, e);
-                    if (isnan(r)) r = 0.;
-                }
-            } else r = 0.;
-            const int acc = (u <= r) ? 1 : 0;
-            s_acc[m] = acc;
-            if (acc) {
-                a.logL_cur[m] = logL;
-                a.logPr_cur[m] = logPr;
-                a.logPost_cur[m] = logPost;
-            }
-            a.moved[m] = acc;
-            a.Pmove[m] = r;
-            if (m == 0 && acc) a.counters[1] += 1;
-        }
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 = s1 + __shfl_down(s1, off, 64);
+        s2 = s2 + __shfl_down(s2, off, 64);
     }
     __syncthreads();
-    for (int m = 0; m < C; m++) {
-        if (s_acc[m]) {
-            for (int i = tid; i < Nv; i += 256) a.vars_cur[(size_t)m * Nv + i] = a.vars_prop[(size_t)m * Nv + i];
-            for (int i = tid; i < Np; i += 256) a.params_cur[(size_t)m * Np + i] = a.params_prop[(size_t)m * Np + i];
-        }
-    }
+    if (lane == 0) { s_red[2 * wave] = s1; s_red[2 * wave + 1] = s2; }
     __syncthreads();
-    // ---- parallel tempering: adjacent pair, tempered log-likelihoods (MALA.cpp:397-461) ----
-    const bool do_swap = a.dN_mixing > 0 && (it % a.dN_mixing == 0) && it != 0 && C > 1;
     if (tid == 0) {
-        s_swapA = -1;
-        if (do_swap) {
-            double u, u2;
-            rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)it, 0, u, u2);
-            int A = (int)(u2 * (double)(C - 1));
-            if (A > C - 2) A = C - 2;
-            const int B = A + 1;
-            const double LA = a.logL_cur[A], LB = a.logL_cur[B];
-            const double LA_TB = LA * a.Tcoefs[A] / a.Tcoefs[B];
-            const double LB_TA = LB * a.Tcoefs[B] / a.Tcoefs[A];
-            const double e = exp(LA_TB + LB_TA - LA - LB);
-            const double rT = fmin(1.0, e);
-            a.counters[2] += 1;
-            if (u <= rT) {
-                s_swapA = A;
-                s_swapvals[0] = LB_TA;
-                s_swapvals[1] = LA_TB;
-                a.counters[3] += 1;
+        double t1 = s_red[0], t2 = s_red[1];
+        for (int w = 1; w < TB / 64; w++) { t1 = t1 + s_red[2 * w]; t2 = t2 + s_red[2 * w + 1]; }
+        const double S = t1 + t2;
+        const int C = a.C;
+        double logL = (-(double)a.pl * S) / a.Tcoefs[j];  // call_likelihood, model_def.cpp:399-401
+        const double logPr = a.logPr_prop[P * C + j];
+        double logPost;
+        if (a.status_prop[P * C + j] != TAMCMC_OK) logL = NAN;
+        if (logPr == -INFINITY || isnan(logPr)) { logL = a.init_logL[j]; logPost = -INFINITY; }  // model_def.cpp:476-480
+        else logPost = logL + logPr;
+        double u, u1;
+        rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)j, (uint64_t)itp, 0, u, u1);
+        double r;
+        if (!isnan(logL)) {
+            if (logPost == -INFINITY) r = 0.;
+            else {
+                const double e = exp(logPost - a.logPost_cur[P * C + j]);
+                r = fmin(1.0, e);
+                if (isnan(r)) r = 0.;
             }
-        }
+        } else r = 0.;
+        AcceptOut o;
+        o.acc = (u <= r) ? 1 : 0;
+        o.r = r;
+        if (o.acc) { o.logL = logL; o.logPr = logPr; o.logPost = logPost; }
+        else { o.logL = a.logL_cur[P * C + j]; o.logPr = a.logPr_cur[P * C + j]; o.logPost = a.logPost_cur[P * C + j]; }
+        *s_out = o;
     }
     __syncthreads();
-    if (s_swapA >= 0) {
-        const int A = s_swapA, B = A + 1;
-        for (int i = tid; i < Nv; i += 256) {
-            const double t = a.vars_cur[(size_t)A * Nv + i];
-            a.vars_cur[(size_t)A * Nv + i] = a.vars_cur[(size_t)B * Nv + i];
-            a.vars_cur[(size_t)B * Nv + i] = t;
-        }
-        for (int i = tid; i < Np; i += 256) {
-            const double t = a.params_cur[(size_t)A * Np + i];
-            a.params_cur[(size_t)A * Np + i] = a.params_cur[(size_t)B * Np + i];
-            a.params_cur[(size_t)B * Np + i] = t;
-        }
-        if (tid == 0) {
-            const double prA = a.logPr_cur[A], prB = a.logPr_cur[B];
-            a.logL_cur[A] = s_swapvals[0];
-            a.logPr_cur[A] = prB;
-            a.logPost_cur[A] = s_swapvals[0] + prB;
-            a.logL_cur[B] = s_swapvals[1];
-            a.logPr_cur[B] = prA;
-            a.logPost_cur[B] = s_swapvals[1] + prA;
-            const int mv = a.moved[A]; a.moved[A] = a.moved[B]; a.moved[B] = mv;
-            const double pm = a.Pmove[A]; a.Pmove[A] = a.Pmove[B]; a.Pmove[B] = pm;
-        }
-    }
-    __syncthreads();
-    // ---- record (update_buffer_params / update_buffer_stat_criteria, MALA.cpp:708-710) ----
-    if (a.samples && rec >= 0)
-        for (int i = tid; i < C * Nv; i += 256) a.samples[(size_t)rec * C * Nv + i] = a.vars_cur[i];
-    if (a.stats && rec >= 0)
-        for (int m = tid; m < C; m += 256) {
-            double *r = a.stats + ((size_t)rec * C + m) * 3;
-            r[0] = a.logL_cur[m];
-            r[1] = a.logPr_cur[m];
-            r[2] = a.logPost_cur[m];
-        }
-    if (tid == 0) a.counters[0] = it + 1;
 }
 
-// Robbins-Monro adaptation + Cholesky, one workgroup per chain (learning phases only).
-__global__ void __launch_bounds__(256) k_adapt(const DevSamplerArgs a, const long it, double *scratch) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    __shared__ double s_red[4];
-    __shared__ double s_scal[2];
-    const int m = blockIdx.x, tid = threadIdx.x, Nv = a.Nv;
-    double *A = a.chol_in_lds ? (double *)s_raw : scratch + (size_t)m * Nv * Nv;
-    double *d = a.chol_in_lds ? (double *)s_raw + (size_t)Nv * Nv : scratch + (size_t)a.C * Nv * Nv + (size_t)m * Nv;
-    const double g = a.c0 / (1. + (double)it);
+// Robbins-Monro adaptation of chain m's proposal law (MALA.cpp:296-319) and Cholesky of (Sigma+eps2 I) sigma
+// (MALA.cpp:348-350); `vars` = the chain's position after the MH test, `Pm` = its move probability.
+__device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const double *vars, double Pm, double *A, double *d,
+                            double *s_red, double *s_scal) {
+    const int tid = threadIdx.x, Nv = a.Nv;
+    const double g = a.c0 / (1. + (double)itp);
     double *mu = a.mu + (size_t)m * Nv;
     double *cov = a.cov + (size_t)m * Nv * Nv;
-    const double *vars = a.vars_cur + (size_t)m * Nv;
-    // mu (MALA.cpp:307-308) with the norm clip p3
     double n2 = 0;
-    for (int k = tid; k < Nv; k += 256) {
+    for (int k = tid; k < Nv; k += TB) {
         const double v = mu[k] + g * (vars[k] - mu[k]);
         d[k] = v;
         n2 += v * v;
@@ -310,17 +128,16 @@ __global__ void __launch_bounds__(256) k_adapt(const DevSamplerArgs a, const lon
     n2 = block_sum(n2, s_red);
     {
         const double nrm = sqrt(n2);
-        const double sc = (nrm <= a.A1) ? 1.0 : a.A1 / nrm;
-        for (int k = tid; k < Nv; k += 256) {
+        const double sc = (nrm <= a.A1) ? 1.0 : a.A1 / nrm;  // p3_fct
+        for (int k = tid; k < Nv; k += TB) {
             const double v = (sc == 1.0) ? d[k] : d[k] * sc;
             mu[k] = v;
             d[k] = vars[k] - v;  // deviation from the UPDATED mu (MALA.cpp:311)
         }
     }
     __syncthreads();
-    // covariance (MALA.cpp:311-313) with the Frobenius clip p2
     n2 = 0;
-    for (int e = tid; e < Nv * Nv; e += 256) {
+    for (int e = tid; e < Nv * Nv; e += TB) {
         const int i = e / Nv, j = e - i * Nv;
         const double v = cov[e] + g * (d[i] * d[j] - cov[e]);
         cov[e] = v;
@@ -329,41 +146,272 @@ __global__ void __launch_bounds__(256) k_adapt(const DevSamplerArgs a, const lon
     n2 = block_sum(n2, s_red);
     if (tid == 0) {
         const double nrm = sqrt(n2);
-        s_scal[0] = (nrm <= a.A1) ? 1.0 : a.A1 / nrm;
-        // sigma (MALA.cpp:316-317) with the clip p1
-        double v1 = a.sigma[m] + g * (a.Pmove[m] - a.target_acceptance);
-        if (v1 < a.epsilon1) v1 = a.epsilon1;
+        s_scal[0] = (nrm <= a.A1) ? 1.0 : a.A1 / nrm;  // p2_fct
+        double v1 = a.sigma[m] + g * (Pm - a.target_acceptance);
+        if (v1 < a.epsilon1) v1 = a.epsilon1;  // p1_fct
         if (v1 > a.A1) v1 = a.A1;
         a.sigma[m] = v1;
         s_scal[1] = v1;
     }
     __syncthreads();
     const double sc = s_scal[0], sig = s_scal[1];
-    for (int e = tid; e < Nv * Nv; e += 256) {
+    for (int e = tid; e < Nv * Nv; e += TB) {
         const int i = e / Nv, j = e - i * Nv;
         double v = cov[e];
         if (sc != 1.0) { v = v * sc; cov[e] = v; }
-        A[e] = (v + (i == j ? a.epsi2 : 0.0)) * sig;  // (covarmat + epsilon2) * sigma (MALA.cpp:348)
+        A[e] = (v + (i == j ? a.epsi2 : 0.0)) * sig;
     }
     __syncthreads();
-    // right-looking Cholesky in place (lower triangle of A)
+    // right-looking Cholesky in place (lower triangle of A): column scale + trailing update per step
     for (int j = 0; j < Nv; j++) {
-        if (tid == 0) A[(size_t)j * Nv + j] = sqrt(A[(size_t)j * Nv + j]);
+        const double djj = sqrt(A[(size_t)j * Nv + j]);
         __syncthreads();
-        const double djj = A[(size_t)j * Nv + j];
-        for (int i = j + 1 + tid; i < Nv; i += 256) A[(size_t)i * Nv + j] = A[(size_t)i * Nv + j] / djj;
+        if (tid == 0) A[(size_t)j * Nv + j] = djj;
+        for (int i = j + 1 + tid; i < Nv; i += TB) A[(size_t)i * Nv + j] = A[(size_t)i * Nv + j] / djj;
         __syncthreads();
         const int rem = Nv - j - 1;
-        for (int e = tid; e < rem * rem; e += 256) {
+        for (int e = tid; e < rem * rem; e += TB) {
             const int i = j + 1 + e / rem, k = j + 1 + e % rem;
             if (k <= i) A[(size_t)i * Nv + k] = A[(size_t)i * Nv + k] - A[(size_t)i * Nv + j] * A[(size_t)k * Nv + j];
         }
         __syncthreads();
     }
     double *LT = a.LT + (size_t)m * Nv * Nv;
-    for (int e = tid; e < Nv * Nv; e += 256) {
+    for (int e = tid; e < Nv * Nv; e += TB) {
         const int i = e / Nv, k = e - i * Nv;
         LT[(size_t)k * Nv + i] = (k <= i) ? A[e] : 0.0;
+    }
+    __syncthreads();
+}
+
+// ONE kernel per MCMC iteration besides the likelihood kernel.  Workgroup m:
+//   (0) settles the pending iteration it-1 for chain m: MH test (own chain; the swap partner's too when chain m is in the
+//       swap pair), adjacent-pair parallel-tempering swap, writes the chain's new current state into the OTHER parity
+//       buffer (no workgroup ever writes what another one reads), records the sample, adapts the proposal law;
+//   (1) proposes iteration `it` from that state: x' = x + L z, log-prior, params' -> multiplet table.
+template <bool PROPOSE>
+__global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const long it, const int P, const int pending,
+                                               const long rec, const int learn_pending, double *scratch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int Np = a.Np, Nv = a.Nv, C = a.C;
+    double *s_params = (double *)s_raw;          // [Np]   current, then proposed parameter vector
+    double *s_vars = s_params + Np;              // [Nv]   current, then proposed variables
+    double *s_z = s_vars + Nv;                   // [Nv+1] normals / post-test position for the adaptation
+    double *s_red = s_z + Nv + 1;                // [8]
+    double *s_w = s_red + 8;                     // [40]   Wigner terms
+    mt::PolyTab *s_poly = (mt::PolyTab *)(s_w + 40);
+    mt::Shared *S = (mt::Shared *)(s_poly + 1);
+    double *s_A = (double *)(((uintptr_t)(S + 1) + 15) & ~(uintptr_t)15);  // [Nv*Nv + Nv] when learning in LDS
+    __shared__ AcceptOut s_own, s_partner;
+    __shared__ int s_status, s_reject;
+    __shared__ double s_dnu, s_scal[2];
+
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int Q = P ^ 1;
+    const double *curv = a.vars_cur + (size_t)P * C * Nv, *curp = a.params_cur + (size_t)P * C * Np;
+    const double *prpv = a.vars_prop + (size_t)P * C * Nv, *prpp = a.params_prop + (size_t)P * C * Np;
+    double *newv = a.vars_cur + (size_t)Q * C * Nv, *newp = a.params_cur + (size_t)Q * C * Np;
+
+    // ------------------------------------------------------------------ (0) settle the pending iteration
+    if (pending) {
+        const long itp = it - 1;
+        accept_result(a, m, itp, P, s_red, &s_own);
+        int src = m;
+        double logL_new = s_own.logL, logPr_new = s_own.logPr, logPost_new = s_own.logPost;
+        // parallel tempering (MALA.cpp:397-461): adjacent pair, tempered log-likelihoods after the MH tests
+        const bool swap_step = a.dN_mixing > 0 && (itp % a.dN_mixing == 0) && itp != 0 && C > 1;
+        if (swap_step) {
+            double u, u2;
+            rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)itp, 0, u, u2);
+            int A = (int)(u2 * (double)(C - 1));
+            if (A > C - 2) A = C - 2;
+            const int B = A + 1;
+            if (m == A || m == B) {  // workgroup-uniform branch
+                const int partner = (m == A) ? B : A;
+                accept_result(a, partner, itp, P, s_red, &s_partner);
+                const double LA = (m == A) ? s_own.logL : s_partner.logL;
+                const double LB = (m == A) ? s_partner.logL : s_own.logL;
+                const double LA_TB = LA * a.Tcoefs[A] / a.Tcoefs[B];
+                const double LB_TA = LB * a.Tcoefs[B] / a.Tcoefs[A];
+                const double e = exp(LA_TB + LB_TA - LA - LB);
+                const double rT = fmin(1.0, e);
+                const bool swapped = (u <= rT);
+                if (swapped) {
+                    src = partner;
+                    logPr_new = s_partner.logPr;
+                    logL_new = (m == A) ? LB_TA : LA_TB;  // re-tempered value of the partner's likelihood
+                    logPost_new = logL_new + logPr_new;
+                }
+                if (m == A && tid == 0) {
+                    a.counters[2] += 1;
+                    if (swapped) a.counters[3] += 1;
+                }
+            }
+        }
+        const int src_acc = (src == m) ? s_own.acc : s_partner.acc;
+        const double *sv = (src_acc ? prpv : curv) + (size_t)src * Nv;
+        const double *sp = (src_acc ? prpp : curp) + (size_t)src * Np;
+        for (int i = tid; i < Nv; i += TB) { const double v = sv[i]; s_vars[i] = v; newv[(size_t)m * Nv + i] = v; }
+        for (int i = tid; i < Np; i += TB) { const double v = sp[i]; s_params[i] = v; newp[(size_t)m * Np + i] = v; }
+        if (learn_pending) {  // the adaptation sees the chain's OWN position after the MH test, before the swap
+            const double *ov = (s_own.acc ? prpv : curv) + (size_t)m * Nv;
+            for (int i = tid; i < Nv; i += TB) s_z[i] = ov[i];
+        }
+        if (tid == 0) {
+            a.logL_cur[Q * C + m] = logL_new;
+            a.logPr_cur[Q * C + m] = logPr_new;
+            a.logPost_cur[Q * C + m] = logPost_new;
+            a.moved[m] = s_own.acc;
+            a.Pmove[m] = s_own.r;
+            if (m == 0 && s_own.acc) a.counters[1] += 1;
+            if (m == 0) a.counters[0] = it;
+            if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
+                double *r = a.stats + ((size_t)rec * C + m) * 3;
+                r[0] = logL_new; r[1] = logPr_new; r[2] = logPost_new;
+            }
+        }
+        __syncthreads();
+        if (a.samples && rec >= 0)  // update_buffer_params (MALA.cpp:710)
+            for (int i = tid; i < Nv; i += TB) a.samples[((size_t)rec * C + m) * Nv + i] = s_vars[i];
+        if (learn_pending) {
+            double *Aw = a.chol_in_lds ? s_A : scratch + (size_t)m * ((size_t)Nv * Nv + Nv);
+            adapt_chain(a, m, itp, s_z, s_own.r, Aw, Aw + (size_t)Nv * Nv, s_red, s_scal);
+        }
+    } else {
+        for (int i = tid; i < Nv; i += TB) { const double v = curv[(size_t)m * Nv + i]; s_vars[i] = v; newv[(size_t)m * Nv + i] = v; }
+        for (int i = tid; i < Np; i += TB) { const double v = curp[(size_t)m * Np + i]; s_params[i] = v; newp[(size_t)m * Np + i] = v; }
+        if (tid == 0) {
+            a.logL_cur[Q * C + m] = a.logL_cur[P * C + m];
+            a.logPr_cur[Q * C + m] = a.logPr_cur[P * C + m];
+            a.logPost_cur[Q * C + m] = a.logPost_cur[P * C + m];
+        }
+    }
+    if (!PROPOSE) return;
+    __syncthreads();
+
+    // ------------------------------------------------------------------ (1) propose iteration `it`
+    // x' = x + L z (MALA.cpp:348-355), L = chol((Sigma+eps2) sigma) stored transposed; same Philox streams as the host engine
+    for (int k2 = tid; 2 * k2 < Nv; k2 += TB) {
+        double z0, z1;
+        rng_normal2(a.seed, RNG_PROPOSAL, (uint32_t)m, (uint64_t)it, (uint32_t)k2, z0, z1);
+        s_z[2 * k2] = z0;
+        s_z[2 * k2 + 1] = z1;
+    }
+    {   // Pslm/Qlm tables into LDS (the per-multiplet lanes index them with their own degree)
+        const double *src = (const double *)a.poly;
+        double *dst = (double *)s_poly;
+        for (int i = tid; i < (int)(sizeof(mt::PolyTab) / sizeof(double)); i += TB) dst[i] = src[i];
+    }
+    if (tid == 0) { s_status = TAMCMC_OK; s_reject = 0; }
+    __syncthreads();
+    const double *LT = a.LT + (size_t)m * Nv * Nv;
+    double *pv = a.vars_prop + (size_t)Q * C * Nv + (size_t)m * Nv;
+    for (int i = tid; i < Nv; i += TB) {  // lane i owns row i: reads s_vars[i] only, every s_z[k]
+        double s = 0;
+        for (int k = 0; k <= i; k++) s = s + LT[(size_t)k * Nv + i] * s_z[k];
+        const double v = s_vars[i] + 0.0 + s;
+        s_vars[i] = v;
+        pv[i] = v;
+    }
+    __syncthreads();
+    for (int k = tid; k < Nv; k += TB) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
+    __syncthreads();
+    for (int i = tid; i < Np; i += TB) a.params_prop[(size_t)Q * C * Np + (size_t)m * Np + i] = s_params[i];
+
+    // ---- log-prior: hard constraints sliced over the lanes, additive terms one per lane, tree-summed ----
+    {
+        int st = TAMCMC_OK;
+        mt::xreal c = 0;
+        if (a.prior_class == 2) {
+            c = pr::ms_global_constraints(s_params, a.plength, a.priors_switch, a.extra, &st, tid, TB);
+            if (tid == 1) {
+                double fit[2];
+                mt::linfit_index(s_params + a.plength[0] + a.plength[1], a.plength[2], fit);
+                s_dnu = fit[0];
+            }
+        } else if (a.prior_class == 3) {
+            if (tid == 0) c = pr::local_constraints(s_params, a.plength, a.priors_switch, a.extra);
+        } else {
+            c = pr::neg_inf();
+            st = TAMCMC_ERR_BAD_MODEL;
+        }
+        if (c != 0) s_reject = 1;
+        if (st != TAMCMC_OK) s_status = st;
+    }
+    __syncthreads();
+    double logPr;
+    {
+        const int n_extra = (a.prior_class == 2) ? pr::ms_global_extra_terms(a.plength, a.extra) : 0;
+        double f = 0;
+        int st = TAMCMC_OK;
+        for (int t = tid; t < Np + n_extra; t += TB) {
+            if (t < Np) f = f + pr::generic_prior_term(s_params, Np, a.priors, a.priors_switch, t, &st);
+            else f = f + pr::ms_global_extra_term(s_params, a.plength, a.extra, s_dnu, t - Np);
+        }
+        if (st != TAMCMC_OK) s_status = st;
+        f = block_sum(f, s_red);
+        logPr = s_reject ? -INFINITY : f;
+    }
+
+    // ---- params' -> multiplet table (skipped when the prior is -inf: model_def.cpp:472,476-480) ----
+    const int per = a.per;
+    const bool live = (logPr != -INFINITY) && !isnan(logPr);
+    if (live) {
+        if (tid == 0) mt::shared_scalars_base(a.model_id, s_params, a.plength, *S);
+        __syncthreads();
+        // m-visibilities (function_rot.cpp): one lane per TERM of each Wigner sum d^l_{i,0}(beta), i=0..l, and of the
+        // centre elements d^l_{0,0}(-beta): element e of degree l has l-i+1 terms; 40 slots
+        {
+            const double PI = 3.141592653589793238462643;
+            const double ang = PI * S->inc / 180.;
+            // slot layout: for l=1..3, for i=0..l (then the centre as i=-1): terms s=0..l-max(i,0)
+            int slot = 0;
+            for (int l = 1; l <= 3; l++)
+                for (int e = 0; e <= l + 1; e++) {
+                    const int i = (e <= l) ? e : 0;
+                    const double b = (e <= l) ? ang : -ang;
+                    for (int s = 0; s <= l - i; s++, slot++)
+                        if (slot == tid && S->need_ratio[l]) s_w[slot] = mt::wigner_term(l, i, 0, b, s);
+                }
+        }
+        __syncthreads();
+        if (tid >= 1 && tid <= 3 && S->need_ratio[tid]) {  // sums in order, mirror, centre overwrite, square
+            const int l = tid;
+            int slot = 0;
+            for (int ll = 1; ll < l; ll++)
+                for (int e = 0; e <= ll + 1; e++) slot += ll - ((e <= ll) ? e : 0) + 1;
+            double *V = S->ratios[l];
+            double centre = 0;
+            for (int e = 0; e <= l + 1; e++) {
+                const int i = (e <= l) ? e : 0;
+                double sum = 0;
+                for (int s = 0; s <= l - i; s++, slot++) sum = sum + s_w[slot];
+                const double d = mt::wigner_finish(l, i, 0, sum);
+                if (e <= l) V[l + i] = d; else centre = d;
+            }
+            for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * pow(-1.0, (double)i);
+            V[l] = centre * pow(-1.0, 0.);
+            for (int i = 0; i <= 2 * l; i++) V[i] = V[i] * V[i];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < per; idx += TB) {
+            tamcmc_multiplet r;
+            const int st = mt::build_multiplet(a.model_id, *s_poly, s_params, *S, idx, a.x_first, a.x_last, a.Nx, a.step, &r);
+            if (st) s_status = st;
+            else a.mults[(size_t)m * per + idx] = r;
+        }
+        for (int i = tid; i < S->L.Nnoise; i += TB) a.noise[(size_t)m * a.stride + i] = fabs(s_params[S->L.o_noise + i]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool ok = live && (s_status == TAMCMC_OK);
+        a.pairs[2 * m] = m * per;
+        a.pairs[2 * m + 1] = ok ? (m + 1) * per : m * per;
+        a.nh[m] = ok ? S->nharvey : 0;
+        a.nn[m] = ok ? S->L.Nnoise : 1;
+        if (!ok) a.noise[(size_t)m * a.stride] = 1.0;  // placeholder row; the chain is rejected at the MH test
+        a.logPr_prop[Q * C + m] = logPr;
+        a.status_prop[Q * C + m] = s_status;
     }
 }
 
@@ -380,7 +428,8 @@ struct DevSampler::Impl {
     bool poly_ready = false;
     double *adapt_scratch = nullptr;
     size_t smp_cap = 0, stat_cap = 0;
-    size_t lds_propose = 0, lds_adapt = 0;
+    size_t lds_base = 0, lds_adapt = 0;
+    int parity = 0;  // which of the two state buffers holds the chains' current state
 
     template <typename T>
     hipError_t dalloc(T **p, size_t n) {
@@ -443,10 +492,11 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(up(d_pl, in.plength, 11, st)); DCHK(up(d_idx, in.index_to_relax, Nv, st)); DCHK(up(d_sw, in.priors_switch, Np, st));
     DCHK(up(d_pr, in.priors, 4 * Np, st)); DCHK(up(d_ex, in.extra_priors, 10, st)); DCHK(up(d_T, in.Tcoefs, C, st));
     a.plength = d_pl; a.index_to_relax = d_idx; a.priors_switch = d_sw; a.priors = d_pr; a.extra = d_ex; a.Tcoefs = d_T;
-    DCHK(I.dalloc(&a.vars_cur, C * Nv)); DCHK(I.dalloc(&a.params_cur, C * Np));
-    DCHK(I.dalloc(&a.vars_prop, C * Nv)); DCHK(I.dalloc(&a.params_prop, C * Np));
-    DCHK(I.dalloc(&a.logL_cur, C)); DCHK(I.dalloc(&a.logPr_cur, C)); DCHK(I.dalloc(&a.logPost_cur, C));
-    DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, C)); DCHK(I.dalloc(&a.status_prop, C));
+    // every per-iteration array exists twice (parity): a workgroup reads parity P and writes parity P^1
+    DCHK(I.dalloc(&a.vars_cur, 2 * C * Nv)); DCHK(I.dalloc(&a.params_cur, 2 * C * Np));
+    DCHK(I.dalloc(&a.vars_prop, 2 * C * Nv)); DCHK(I.dalloc(&a.params_prop, 2 * C * Np));
+    DCHK(I.dalloc(&a.logL_cur, 2 * C)); DCHK(I.dalloc(&a.logPr_cur, 2 * C)); DCHK(I.dalloc(&a.logPost_cur, 2 * C));
+    DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * C)); DCHK(I.dalloc(&a.status_prop, 2 * C));
     DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 4));
     DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, C * (size_t)a.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * C)); DCHK(I.dalloc(&a.nh, C)); DCHK(I.dalloc(&a.nn, C));
@@ -455,13 +505,15 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(hipMemsetAsync(a.moved, 0, C * sizeof(int), st));
     DCHK(hipMemsetAsync(a.Pmove, 0, C * sizeof(double), st));
     a.samples = nullptr; a.stats = nullptr;
-    // Cholesky workspace: LDS when (Nv^2 + Nv) doubles fit in 160 KB, else global scratch
+    // Cholesky workspace: LDS when (Nv^2 + Nv) doubles fit beside the iteration's own LDS, else global scratch
+    I.lds_base = (Np + 2 * Nv + 1 + 8 + 40) * sizeof(double) + sizeof(mt::PolyTab) + sizeof(mt::Shared) + 64;
     I.lds_adapt = (Nv * Nv + Nv) * sizeof(double);
-    a.chol_in_lds = I.lds_adapt <= 150 * 1024 ? 1 : 0;
-    if (!a.chol_in_lds) { DCHK(I.dalloc(&I.adapt_scratch, C * Nv * Nv + C * Nv)); I.lds_adapt = 0; }
-    I.lds_propose = (Np + 2 * Nv + 1 + 4) * sizeof(double) + sizeof(mt::Shared) + 64;
-    if (I.lds_adapt > 64 * 1024)
-        DCHK(hipFuncSetAttribute((const void *)k_adapt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_adapt));
+    a.chol_in_lds = (I.lds_base + I.lds_adapt <= 156 * 1024) ? 1 : 0;
+    if (!a.chol_in_lds) { DCHK(I.dalloc(&I.adapt_scratch, C * (Nv * Nv + Nv))); I.lds_adapt = 0; }
+    if (I.lds_base + I.lds_adapt > 64 * 1024) {
+        DCHK(hipFuncSetAttribute((const void *)k_iterate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(I.lds_base + I.lds_adapt)));
+        DCHK(hipFuncSetAttribute((const void *)k_iterate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(I.lds_base + I.lds_adapt)));
+    }
     // polynomial tables Pslm/Qlm: computed ON the device (its own double arithmetic), read through a uniform pointer
     mt::PolyTab *d_tab;
     DCHK(I.dalloc(&d_tab, 1));
@@ -481,8 +533,9 @@ int DevSampler::upload_state(const double *vars, const double *params, const dou
     const size_t C = (size_t)a.C, Np = (size_t)a.Np, Nv = (size_t)a.Nv;
     hipStream_t st = c->stream;
     DCHK(hipSetDevice(c->device));
-    DCHK(up(a.vars_cur, vars, C * Nv, st)); DCHK(up(a.params_cur, params, C * Np, st));
-    DCHK(up(a.logL_cur, logL, C, st)); DCHK(up(a.logPr_cur, logPr, C, st)); DCHK(up(a.logPost_cur, logPost, C, st));
+    const size_t P = (size_t)I.parity;
+    DCHK(up(a.vars_cur + P * C * Nv, vars, C * Nv, st)); DCHK(up(a.params_cur + P * C * Np, params, C * Np, st));
+    DCHK(up(a.logL_cur + P * C, logL, C, st)); DCHK(up(a.logPr_cur + P * C, logPr, C, st)); DCHK(up(a.logPost_cur + P * C, logPost, C, st));
     DCHK(up(a.init_logL, init_logL, C, st));
     DCHK(hipStreamSynchronize(st));
     return TAMCMC_OK;
@@ -515,11 +568,12 @@ int DevSampler::download_state(double *vars, double *params, double *logL, doubl
     hipStream_t st = c->stream;
     DCHK(hipSetDevice(c->device));
     auto down = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st); };
-    if (vars) DCHK(down(vars, a.vars_cur, C * Nv * 8));
-    if (params) DCHK(down(params, a.params_cur, C * Np * 8));
-    if (logL) DCHK(down(logL, a.logL_cur, C * 8));
-    if (logPr) DCHK(down(logPr, a.logPr_cur, C * 8));
-    if (logPost) DCHK(down(logPost, a.logPost_cur, C * 8));
+    const size_t P = (size_t)I.parity;
+    if (vars) DCHK(down(vars, a.vars_cur + P * C * Nv, C * Nv * 8));
+    if (params) DCHK(down(params, a.params_cur + P * C * Np, C * Np * 8));
+    if (logL) DCHK(down(logL, a.logL_cur + P * C, C * 8));
+    if (logPr) DCHK(down(logPr, a.logPr_cur + P * C, C * 8));
+    if (logPost) DCHK(down(logPost, a.logPost_cur + P * C, C * 8));
     if (Pmove) DCHK(down(Pmove, a.Pmove, C * 8));
     if (moved) DCHK(down(moved, a.moved, C * sizeof(int)));
     if (counters) DCHK(down(counters, a.counters, 4 * sizeof(long)));
@@ -572,16 +626,26 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     const bool fast = c->precision == TAMCMC_PRECISION_FAST;
     int used_ev = 0;
     const long ev_every = n_iter > 64 ? n_iter / 64 : 1;
-    for (long i = 0; i < n_iter; i++) {
+    int P = I.parity, pending = 0;
+    for (long i = 0; i <= n_iter; i++) {
         const long it = it0 + i;
-        hipLaunchKernelGGL(k_propose_unpack, dim3(a.C), dim3(PB), I.lds_propose, st, args, it);
-        const bool timed = c->timing && (i % ev_every == 0) && used_ev < I.n_ev;
-        if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
-        DCHK(launch_loglike(la, fast, c->K, false, st));
-        if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
-        hipLaunchKernelGGL(k_accept_swap, dim3(1), dim3(256), 0, st, args, it, (samples || stats) ? i : (long)-1);
-        if (learn && learn[i]) hipLaunchKernelGGL(k_adapt, dim3(a.C), dim3(256), I.lds_adapt, st, args, it, I.adapt_scratch);
+        const int learn_p = (pending && learn && learn[i - 1]) ? 1 : 0;
+        const size_t lds = I.lds_base + ((learn_p && a.chol_in_lds) ? I.lds_adapt : 0);
+        const long rec = (pending && (samples || stats)) ? i - 1 : (long)-1;
+        if (i < n_iter) {
+            hipLaunchKernelGGL(k_iterate<true>, dim3(a.C), dim3(TB), lds, st, args, it, P, pending, rec, learn_p, I.adapt_scratch);
+            P ^= 1;
+            pending = 1;
+            const bool timed = c->timing && (i % ev_every == 0) && used_ev < I.n_ev;
+            if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
+            DCHK(launch_loglike(la, fast, c->K, false, st));
+            if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
+        } else {  // settle the last iteration of this run (MH test, swap, record, adaptation); nothing is proposed
+            hipLaunchKernelGGL(k_iterate<false>, dim3(a.C), dim3(TB), lds, st, args, it, P, pending, rec, learn_p, I.adapt_scratch);
+            P ^= 1;
+        }
     }
+    I.parity = P;
     DCHK(hipGetLastError());
     if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));

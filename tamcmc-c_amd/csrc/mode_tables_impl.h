@@ -104,16 +104,21 @@ TM_HD int ifact(int n) {
     return (int)f;
 }
 TM_HD double icombi(int n, int r) { return (double)(ifact(n) / ifact(n - r) / ifact(r)); }
-TM_HD double wigner_d(int l, int m1, int m2, double beta) {
-    double sum = 0;
-    for (long s = 0; s <= l - m1; s++) {
-        double v = icombi(l + m2, (int)(l - m1 - s)) * icombi(l - m2, (int)s) * pow(-1.0, (double)(l - m1 - s));
-        v = v * pow(cos(beta / 2.), (double)(2 * s + m1 + m2)) * pow(sin(beta / 2.), (double)(2 * l - 2 * s - m1 - m2));
-        sum = sum + v;
-    }
+// one term of the sum over s in dmm() and the normalisation applied after the loop (function_rot.cpp:76-88)
+TM_HD double wigner_term(int l, int m1, int m2, double beta, long s) {
+    double v = icombi(l + m2, (int)(l - m1 - s)) * icombi(l - m2, (int)s) * pow(-1.0, (double)(l - m1 - s));
+    v = v * pow(cos(beta / 2.), (double)(2 * s + m1 + m2)) * pow(sin(beta / 2.), (double)(2 * l - 2 * s - m1 - m2));
+    return v;
+}
+TM_HD double wigner_finish(int l, int m1, int m2, double sum) {
     sum = sum * sqrt((double)(ifact(l + m1) * ifact(l - m1)));
     sum = sum / sqrt((double)(ifact(l + m2) * ifact(l - m2)));
     return sum;
+}
+TM_HD double wigner_d(int l, int m1, int m2, double beta) {
+    double sum = 0;
+    for (long s = 0; s <= l - m1; s++) sum = sum + wigner_term(l, m1, m2, beta, s);
+    return wigner_finish(l, m1, m2, sum);
 }
 TM_HD void amplitude_ratio(int l, double beta_deg, double *V) {
     const double PI = 3.141592653589793238462643;

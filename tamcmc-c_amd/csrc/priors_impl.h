@@ -32,7 +32,7 @@ TM_HD xreal xsqrt(xreal v) {
 }
 TM_HD xreal xpow2(xreal v) {  // pow(v, 2.)
 #if defined(__HIP_DEVICE_COMPILE__)
-    return pow(v, 2.);
+    return v * v;  // a correctly rounded pow(v,2) IS v*v; the device pow() costs ~150 fp64 issue slots
 #else
     return powl(v, 2.);
 #endif
@@ -114,8 +114,11 @@ TM_HD double second_difference(const double *y, long n, long i) {
 }
 
 // ---- priors_MS_Global split into: hard constraints (-inf or 0) and a list of additive terms ----
-// hard constraints: visibilities >= 0, |aj/a1| limits (model_index 9), Harvey parameters >= 0
-TM_HD xreal ms_global_constraints(const double *params, const int *pl, const int *sw, const double *extra, int *status) {
+// hard constraints: visibilities >= 0, |aj/a1| limits (model_index 9), Harvey parameters >= 0.
+// The checks are independent: check number t0, t0+stride, ... are evaluated (host: t0=0, stride=1 = all of them in the
+// reference's order; device: one slice per lane, results OR-ed).  Returns 0 or -inf.
+TM_HD xreal ms_global_constraints(const double *params, const int *pl, const int *sw, const double *extra, int *status,
+                                  int t0 = 0, int stride = 1) {
     const double *ajova1_limit = &extra[2];
     const int impose_normHnlm = (int)extra[8];
     const int model_index = (int)extra[9];
@@ -123,14 +126,16 @@ TM_HD xreal ms_global_constraints(const double *params, const int *pl, const int
     const int Nfl[4] = {pl[2], pl[3], pl[4], pl[5]};
     const int Nsplit = pl[6], Nwidth = pl[7];
     const int Nf = Nfl[0] + Nfl[1] + Nfl[2] + Nfl[3];
-    for (int i = Nmax; i <= Nmax + lmax; i++)  // priors_calc.cpp:63-68
-        if (params[i] < 0) return neg_inf();
+    int t = 0;  // running check index
+    for (int i = Nmax; i <= Nmax + lmax; i++, t++)  // priors_calc.cpp:63-68
+        if ((t - t0) % stride == 0 && t >= t0 && params[i] < 0) return neg_inf();
     switch (model_index) {
     case 9: {  // priors_calc.cpp:206-228
         int i0 = Nfl[0];
         for (int el = 1; el < lmax + 1; el++) {
             for (int j = 1; j < 6; j++) {
-                for (int n = 0; n < Nfl[el]; n++) {
+                for (int n = 0; n < Nfl[el]; n++, t++) {
+                    if (t < t0 || (t - t0) % stride != 0) continue;
                     const double fl = params[Nmax + lmax + i0 + n];
                     const double a1 = params[Nmax + lmax + Nf] + params[Nmax + lmax + Nf + 1] * (fl * 1e-3);
                     const double aj = params[Nmax + lmax + Nf + 2 * j] + params[Nmax + lmax + Nf + 2 * j + 1] * (fl * 1e-3);
@@ -152,6 +157,7 @@ TM_HD xreal ms_global_constraints(const double *params, const int *pl, const int
         }
         break;
     }
+    if (t0 != 0) return 0;  // the three noise checks belong to slice 0
     const int on = Nmax + lmax + Nf + Nsplit + Nwidth;  // noise block
     if (sw[on + 3] != 0)
         if ((params[on + 3] < 0) || (params[on + 4] < 0) || (params[on + 5] < 0)) return neg_inf();
