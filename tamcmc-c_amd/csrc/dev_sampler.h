@@ -25,6 +25,7 @@ struct DevSamplerArgs {
     double *vars_prop, *params_prop, *logPr_prop;
     int *status_prop, *moved;
     double *Pmove;
+    long *dbg;            // optional phase stamps (TAMCMC_DEBUG_STAMPS=1)
     long *counters;       // [0] iteration, [1] accepted moves of chain 0, [2] swap attempts, [3] swaps accepted
     // proposal law
     double *LT, *cov, *mu, *sigma;   // LT = transposed Cholesky factor of (cov+eps2)*sigma

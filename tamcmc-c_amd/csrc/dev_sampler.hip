@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -208,6 +210,8 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
 
     const int m = blockIdx.x, tid = threadIdx.x;
     const int Q = P ^ 1;
+#define STAMP(k) do { if (a.dbg && m == 0 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
+    STAMP(0);
     const double *curv = a.vars_cur + (size_t)P * C * Nv, *curp = a.params_cur + (size_t)P * C * Np;
     const double *prpv = a.vars_prop + (size_t)P * C * Nv, *prpp = a.params_prop + (size_t)P * C * Np;
     double *newv = a.vars_cur + (size_t)Q * C * Nv, *newp = a.params_cur + (size_t)Q * C * Np;
@@ -286,6 +290,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
             a.logPost_cur[Q * C + m] = a.logPost_cur[P * C + m];
         }
     }
+    STAMP(1);
     if (!PROPOSE) return;
     __syncthreads();
 
@@ -314,6 +319,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
         pv[i] = v;
     }
     __syncthreads();
+    STAMP(2);
     for (int k = tid; k < Nv; k += TB) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
     __syncthreads();
     for (int i = tid; i < Np; i += TB) a.params_prop[(size_t)Q * C * Np + (size_t)m * Np + i] = s_params[i];
@@ -339,6 +345,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
         if (st != TAMCMC_OK) s_status = st;
     }
     __syncthreads();
+    STAMP(3);
     double logPr;
     {
         const int n_extra = (a.prior_class == 2) ? pr::ms_global_extra_terms(a.plength, a.extra) : 0;
@@ -353,6 +360,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
         logPr = s_reject ? -INFINITY : f;
     }
 
+    STAMP(4);
     // ---- params' -> multiplet table (skipped when the prior is -inf: model_def.cpp:472,476-480) ----
     const int per = a.per;
     const bool live = (logPr != -INFINITY) && !isnan(logPr);
@@ -364,15 +372,17 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
         {
             const double PI = 3.141592653589793238462643;
             const double ang = PI * S->inc / 180.;
-            // slot layout: for l=1..3, for i=0..l (then the centre as i=-1): terms s=0..l-max(i,0)
-            int slot = 0;
+            // slot layout: for l=1..3, for i=0..l, then the centre (i=0, -beta): terms s=0..l-i.
+            // Each lane first FINDS its (l, i, s), then all lanes evaluate their term together (no divergent calls).
+            int slot = 0, my_l = 0, my_i = 0, my_s = 0;
+            double my_b = 0;
             for (int l = 1; l <= 3; l++)
                 for (int e = 0; e <= l + 1; e++) {
                     const int i = (e <= l) ? e : 0;
-                    const double b = (e <= l) ? ang : -ang;
                     for (int s = 0; s <= l - i; s++, slot++)
-                        if (slot == tid && S->need_ratio[l]) s_w[slot] = mt::wigner_term(l, i, 0, b, s);
+                        if (slot == tid) { my_l = l; my_i = i; my_s = s; my_b = (e <= l) ? ang : -ang; }
                 }
+            if (my_l > 0 && S->need_ratio[my_l]) s_w[tid] = mt::wigner_term(my_l, my_i, 0, my_b, my_s);
         }
         __syncthreads();
         if (tid >= 1 && tid <= 3 && S->need_ratio[tid]) {  // sums in order, mirror, centre overwrite, square
@@ -389,16 +399,16 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
                 const double d = mt::wigner_finish(l, i, 0, sum);
                 if (e <= l) V[l + i] = d; else centre = d;
             }
-            for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * pow(-1.0, (double)i);
-            V[l] = centre * pow(-1.0, 0.);
+            for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * mt::pow_m1(i);
+            V[l] = centre * mt::pow_m1(0);
             for (int i = 0; i <= 2 * l; i++) V[i] = V[i] * V[i];
         }
         __syncthreads();
-        for (int idx = tid; idx < per; idx += TB) {
-            tamcmc_multiplet r;
-            const int st = mt::build_multiplet(a.model_id, *s_poly, s_params, *S, idx, a.x_first, a.x_last, a.Nx, a.step, &r);
+        STAMP(5);
+        for (int idx = tid; idx < per; idx += TB) {  // rows go straight to the likelihood kernel's table (no private copy)
+            const int st = mt::build_multiplet(a.model_id, *s_poly, s_params, *S, idx, a.x_first, a.x_last, a.Nx, a.step,
+                                               &a.mults[(size_t)m * per + idx]);
             if (st) s_status = st;
-            else a.mults[(size_t)m * per + idx] = r;
         }
         for (int i = tid; i < S->L.Nnoise; i += TB) a.noise[(size_t)m * a.stride + i] = fabs(s_params[S->L.o_noise + i]);
     }
@@ -413,6 +423,8 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
         a.logPr_prop[Q * C + m] = logPr;
         a.status_prop[Q * C + m] = s_status;
     }
+    STAMP(6);
+#undef STAMP
 }
 
 }  // namespace
@@ -498,6 +510,8 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.logL_cur, 2 * C)); DCHK(I.dalloc(&a.logPr_cur, 2 * C)); DCHK(I.dalloc(&a.logPost_cur, 2 * C));
     DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * C)); DCHK(I.dalloc(&a.status_prop, 2 * C));
     DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 4));
+    a.dbg = nullptr;
+    if (getenv("TAMCMC_DEBUG_STAMPS")) { DCHK(I.dalloc(&a.dbg, 16)); DCHK(hipMemsetAsync(a.dbg, 0, 16 * sizeof(long), st)); }
     DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, C * (size_t)a.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * C)); DCHK(I.dalloc(&a.nh, C)); DCHK(I.dalloc(&a.nn, C));
     DCHK(I.dalloc(&a.noise, C * (size_t)a.stride));
@@ -646,6 +660,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         }
     }
     I.parity = P;
+    if (a.dbg) {  // phase stamps of the last k_iterate<true> launch (100 MHz wall clock), workgroup 0
+        long h[8];
+        DCHK(hipMemcpyAsync(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost, st));
+        DCHK(hipStreamSynchronize(st));
+        fprintf(stderr, "[k_iterate stamps us] settle %.2f | rng+matvec %.2f | scatter+constraints %.2f | prior terms %.2f | shared+wigner %.2f | multiplets %.2f\n",
+                (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01, (h[6] - h[5]) * 0.01);
+    }
     DCHK(hipGetLastError());
     if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));

@@ -104,10 +104,29 @@ TM_HD int ifact(int n) {
     return (int)f;
 }
 TM_HD double icombi(int n, int r) { return (double)(ifact(n) / ifact(n - r) / ifact(r)); }
+// (-1)^n and x^n for small integer n.  Host: libm pow(), exactly what the reference calls.  Device: sign flip /
+// repeated multiplication (pow() on the GPU costs ~150 fp64 issue slots and serialises a lone lane for microseconds);
+// (-1)^n is exact either way, x^n agrees with pow() to <= 3 ulp for n <= 6.
+TM_HD double pow_m1(int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (n & 1) ? -1.0 : 1.0;
+#else
+    return pow(-1.0, (double)n);
+#endif
+}
+TM_HD double pow_int(double x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = 1.0;
+    for (int i = 0; i < n; i++) r = r * x;
+    return r;
+#else
+    return pow(x, (double)n);
+#endif
+}
 // one term of the sum over s in dmm() and the normalisation applied after the loop (function_rot.cpp:76-88)
 TM_HD double wigner_term(int l, int m1, int m2, double beta, long s) {
-    double v = icombi(l + m2, (int)(l - m1 - s)) * icombi(l - m2, (int)s) * pow(-1.0, (double)(l - m1 - s));
-    v = v * pow(cos(beta / 2.), (double)(2 * s + m1 + m2)) * pow(sin(beta / 2.), (double)(2 * l - 2 * s - m1 - m2));
+    double v = icombi(l + m2, (int)(l - m1 - s)) * icombi(l - m2, (int)s) * pow_m1((int)(l - m1 - s));
+    v = v * pow_int(cos(beta / 2.), (int)(2 * s + m1 + m2)) * pow_int(sin(beta / 2.), (int)(2 * l - 2 * s - m1 - m2));
     return v;
 }
 TM_HD double wigner_finish(int l, int m1, int m2, double sum) {
@@ -125,9 +144,9 @@ TM_HD void amplitude_ratio(int l, double beta_deg, double *V) {
     const double ang = PI * beta_deg / 180.;
     // centre column (m'=0) of the rotation matrix as the four fill passes of function_rot() leave it
     for (int i = 0; i <= l; i++) V[l + i] = wigner_d(l, i, 0, ang);
-    for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * pow(-1.0, (double)i);
+    for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * pow_m1(i);
     V[l] = wigner_d(l, 0, 0, -ang);
-    V[l] = V[l] * pow(-1.0, 0.);
+    V[l] = V[l] * pow_m1(0);
     for (int i = 0; i <= 2 * l; i++) V[i] = V[i] * V[i];
 }
 

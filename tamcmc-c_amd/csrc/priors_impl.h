@@ -126,27 +126,27 @@ TM_HD xreal ms_global_constraints(const double *params, const int *pl, const int
     const int Nfl[4] = {pl[2], pl[3], pl[4], pl[5]};
     const int Nsplit = pl[6], Nwidth = pl[7];
     const int Nf = Nfl[0] + Nfl[1] + Nfl[2] + Nfl[3];
-    int t = 0;  // running check index
-    for (int i = Nmax; i <= Nmax + lmax; i++, t++)  // priors_calc.cpp:63-68
-        if ((t - t0) % stride == 0 && t >= t0 && params[i] < 0) return neg_inf();
-    switch (model_index) {
-    case 9: {  // priors_calc.cpp:206-228
-        int i0 = Nfl[0];
-        for (int el = 1; el < lmax + 1; el++) {
-            for (int j = 1; j < 6; j++) {
-                for (int n = 0; n < Nfl[el]; n++, t++) {
-                    if (t < t0 || (t - t0) % stride != 0) continue;
-                    const double fl = params[Nmax + lmax + i0 + n];
-                    const double a1 = params[Nmax + lmax + Nf] + params[Nmax + lmax + Nf + 1] * (fl * 1e-3);
-                    const double aj = params[Nmax + lmax + Nf + 2 * j] + params[Nmax + lmax + Nf + 2 * j + 1] * (fl * 1e-3);
-                    if (fabs(aj / a1) >= ajova1_limit[j]) return neg_inf();
-                    if (a1 < 0) return neg_inf();
-                }
-            }
-            i0 = i0 + Nfl[el];
+    // check index space: [0, lmax] visibilities, then for model_index 9 the (el, j, n) grid
+    const int n_vis = lmax + 1;
+    int n_aj = 0;
+    if (model_index == 9)
+        for (int el = 1; el < lmax + 1 && el < 4; el++) n_aj += 5 * Nfl[el];
+    for (int t = t0; t < n_vis + n_aj; t += stride) {
+        if (t < n_vis) {  // priors_calc.cpp:63-68
+            if (params[Nmax + t] < 0) return neg_inf();
+            continue;
         }
-        break;
+        int r = t - n_vis, el = 1, i0 = Nfl[0];  // priors_calc.cpp:206-228
+        while (el < 3 && r >= 5 * Nfl[el]) { r -= 5 * Nfl[el]; i0 += Nfl[el]; el++; }
+        const int j = 1 + r / Nfl[el], n = r % Nfl[el];
+        const double fl = params[Nmax + lmax + i0 + n];
+        const double a1 = params[Nmax + lmax + Nf] + params[Nmax + lmax + Nf + 1] * (fl * 1e-3);
+        const double aj = params[Nmax + lmax + Nf + 2 * j] + params[Nmax + lmax + Nf + 2 * j + 1] * (fl * 1e-3);
+        if (fabs(aj / a1) >= ajova1_limit[j]) return neg_inf();
+        if (a1 < 0) return neg_inf();
     }
+    switch (model_index) {
+    case 9: break;
     case 0: case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8:
         if (status) *status = TAMCMC_ERR_BAD_MODEL;  // families without a table builder in this build
         return neg_inf();
