@@ -44,10 +44,12 @@ extern "C" {
 /* ---------------- arithmetic modes ---------------- */
 /* STRICT: per-bin operation order of the reference (IEEE divides, no FMA contraction): the model row is
  *         bit-identical to the CPU restatement when the Harvey pow() terms are inactive.
- * FAST  : same function, re-associated (common-denominator multiplet sum, reciprocal+Newton, exp/log Harvey);
- *         stated tolerance: |dM|/M <= 1e-12 per bin, |dlogL|/|logL| <= 1e-11. */
+ * FAST  : same function, re-associated (common-denominator multiplet sum, reciprocal+Newton, exp/log Harvey) and,
+ *         for multiplets far from a tile, summed as ONE degree-15 polynomial per tile (truncation <= 8^-16 of the far
+ *         term); stated tolerance: |dM|/M <= 1e-12 per bin, |dlogL|/|logL| <= 1e-11. */
 #define TAMCMC_PRECISION_STRICT 0
-#define TAMCMC_PRECISION_FAST 1
+#define TAMCMC_PRECISION_FAST 1        /* far-field expansion per tile + direct near field */
+#define TAMCMC_PRECISION_FAST_DIRECT 2 /* FAST arithmetic, every component evaluated per bin (no far field) */
 
 #define TAMCMC_OPT_PRECISION 1   /* value: TAMCMC_PRECISION_* (default STRICT) */
 #define TAMCMC_OPT_TIMING 2      /* value: 0/1 -- bracket the likelihood kernel with HIP events on the context stream */
@@ -85,8 +87,8 @@ int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *ctx, const double *x, const double *
  *   call_model  (model_def.cpp:220-388 -> optimum_lorentzian_calc_* + harvey_like, noise_models.cpp:15-39)
  *   call_likelihood (model_def.cpp:390-419 -> likelihood_chi22p, likelihoods.cpp:17-28).
  * mults[offsets[b] .. offsets[b+1]) are evaluation b's multiplets in the reference's accumulation order;
- * noise + b*noise_stride = |noise params| [H0,tau0,p0,...,N0] with nharvey[b] Harvey terms, white noise at
- * index 3*nharvey[b] ... the LAST of the b-th row's nnoise[b] entries;
+ * noise + b*noise_stride = the nnoise[b] values |noise params| = [H0,tau0,p0, H1,tau1,p1, ..., N0] of evaluation b:
+ * nharvey[b] Harvey triples are applied (noise_models.cpp:29-36), the white noise N0 is the LAST of the nnoise[b] entries;
  * Tcoefs[b] = temperature (NULL -> 1); p = likelihood_params truncated to long.
  * Out: logL[b] = -p * sum_i(y_i/M_i + ln M_i) / Tcoefs[b]; model (may be NULL) = B x Nx rows.
  * A non-finite model gives a NaN/inf logL that the caller rejects (MALA.cpp:490,522-524). */

@@ -58,7 +58,8 @@ int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
     if (!c) return TAMCMC_ERR_BAD_ARG;
     switch (option) {
     case TAMCMC_OPT_PRECISION:
-        if (value != TAMCMC_PRECISION_STRICT && value != TAMCMC_PRECISION_FAST) return TAMCMC_ERR_BAD_ARG;
+        if (value != TAMCMC_PRECISION_STRICT && value != TAMCMC_PRECISION_FAST && value != TAMCMC_PRECISION_FAST_DIRECT)
+            return TAMCMC_ERR_BAD_ARG;
         c->precision = (int)value;
         return TAMCMC_OK;
     case TAMCMC_OPT_TIMING: c->timing = value ? 1 : 0; return TAMCMC_OK;
@@ -103,6 +104,7 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
 
     tamcmc::LoglikeArgs a;
     a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.B = B; a.ntiles = ntiles;
+    a.x0 = c->hx[0]; a.step = c->hx[1] - c->hx[0];
     a.mults = (const tamcmc_multiplet *)(c->d_stage.p + L.off_mults);
     a.offsets = (const int32_t *)(c->d_stage.p + L.off_pairs);
     a.noise = (const double *)(c->d_stage.p + L.off_noise);
@@ -112,7 +114,7 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     a.partials = c->d_part.p;
     a.model = model ? c->d_model.p : nullptr;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
-    HIPCHK(c, tamcmc::launch_loglike(a, c->precision == TAMCMC_PRECISION_FAST, c->K, model != nullptr, st));
+    HIPCHK(c, tamcmc::launch_loglike(a, c->precision, c->K, model != nullptr, st));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, tamcmc::launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
     HIPCHK(c, hipMemcpyAsync(c->h_S.p, c->d_S.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -635,9 +635,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     if (!stats) args.stats = nullptr;
     LoglikeArgs la;
     la.x = c->dx.p; la.y = c->dy.p; la.logx = c->dlogx.p; la.Nx = a.Nx; la.B = a.C; la.ntiles = a.ntiles;
+    la.x0 = a.x_first; la.step = a.step;
     la.mults = a.mults; la.offsets = a.pairs; la.noise = a.noise; la.noise_stride = a.stride;
     la.nharvey = a.nh; la.nnoise = a.nn; la.partials = a.partials; la.model = nullptr;
-    const bool fast = c->precision == TAMCMC_PRECISION_FAST;
     int used_ev = 0;
     const long ev_every = n_iter > 64 ? n_iter / 64 : 1;
     int P = I.parity, pending = 0;
@@ -652,7 +652,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             pending = 1;
             const bool timed = c->timing && (i % ev_every == 0) && used_ev < I.n_ev;
             if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
-            DCHK(launch_loglike(la, fast, c->K, false, st));
+            DCHK(launch_loglike(la, c->precision, c->K, false, st));
             if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
         } else {  // settle the last iteration of this run (MH test, swap, record, adaptation); nothing is proposed
             hipLaunchKernelGGL(k_iterate<false>, dim3(a.C), dim3(TB), lds, st, args, it, P, pending, rec, learn_p, I.adapt_scratch);

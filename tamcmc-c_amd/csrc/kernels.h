@@ -14,6 +14,7 @@ struct LoglikeArgs {
     const double *y;      // [Nx] power, resident
     const double *logx;   // [Nx] ln(x) (FAST Harvey terms), resident
     int Nx;
+    double x0, step;      // regular grid: x[i] = x0 + i*step (far-field tile geometry)
     int B;                // evaluations in this launch
     int ntiles;           // filled by launch_loglike
     const tamcmc_multiplet *mults;  // concatenated multiplet tables
@@ -27,7 +28,8 @@ struct LoglikeArgs {
 };
 
 int tile_bins(int K);
-hipError_t launch_loglike(LoglikeArgs a, bool fast, int K, bool write_model, hipStream_t st);
+// mode = TAMCMC_PRECISION_* (0 strict, 1 fast = far-field expansion + direct near field, 2 fast without the far field)
+hipError_t launch_loglike(LoglikeArgs a, int mode, int K, bool write_model, hipStream_t st);
 hipError_t launch_finalize(const double *partials, int B, int ntiles, double *S, hipStream_t st);
 
 }  // namespace tamcmc

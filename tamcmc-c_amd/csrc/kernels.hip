@@ -37,6 +37,18 @@ constexpr int F_FULL = 1;  // window covers every bin of the tile
 constexpr int F_SAFE = 2;  // FAST: product of the 2l+1 denominators stays far below DBL_MAX on this tile
 constexpr int F_ASYM = 4;  // asymmetry coefficient != 0
 
+// arithmetic modes of k_loglike (see include/tamcmc_hip.h)
+constexpr int M_STRICT = 0, M_FAST_DIRECT = 2, M_FAST = 1;
+
+// FAST far field: a multiplet whose window covers the whole tile and whose components all sit at least 1/RHO_MAX tile
+// half-widths away from the tile centre is an analytic function of x on the tile; the sum of ALL such multiplets is ONE
+// polynomial of degree NC-1 in s = (x - x_c)/h, evaluated per bin by Horner (NC-1 fma) instead of ~6 ops per component.
+// Component: hv/(1+(beta s - A)^2) = sum_k c_k s^k, c_k = -hv Im(u q^k), u = 1/(A+i), q = beta u, |q| = rho, with the
+// three-term recurrence c_{k+1} = 2 Re(q) c_k - |q|^2 c_{k-1}.  Truncation error <= rho^NC/(1-rho) of the (small) far term.
+constexpr int NC = 16;
+constexpr double RHO_MAX2 = 0.125 * 0.125;  // rho <= 1/8  ->  8^-16 = 3.6e-15
+constexpr int ROW = NC + 2;  // LDS row stride of the coefficient reduction (16-byte aligned, conflict-free b128 writes)
+
 // LDS image of a multiplet (160 B, every field group 16-byte aligned for ds_read_b128).
 struct __attribute__((aligned(16))) LdsMult {
     int i0, i1, l, flags;
@@ -203,10 +215,20 @@ __device__ __forceinline__ void mult_dispatch(const LdsMult &M, const double (&x
     }
 }
 
-template <bool FAST, int K, bool WRITE_MODEL>
+template <int MODE, int K, bool WRITE_MODEL>
 __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
-    __shared__ LdsMult s_m[CHUNK];
-    __shared__ int s_n;
+    constexpr bool FAST = (MODE != M_STRICT);
+    constexpr bool FARFIELD = (MODE == M_FAST);
+    // near list and (after the multiplet loop) the coefficient-reduction rows share one LDS region
+    constexpr int LDS_BYTES = FARFIELD ? (WG * ROW * 8 > CHUNK * (int)sizeof(LdsMult) ? WG * ROW * 8 : CHUNK * (int)sizeof(LdsMult))
+                                       : CHUNK * (int)sizeof(LdsMult);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[LDS_BYTES];
+    LdsMult *s_m = (LdsMult *)s_buf;
+    double *s_rows = (double *)s_buf;
+    __shared__ int s_n, s_nfar, s_anyfar;
+    __shared__ int s_far[CHUNK];          // FARFIELD: global indices of this chunk's far multiplets
+    __shared__ double s_coef[NC];         // FARFIELD: the tile's far-field polynomial
+    __shared__ double s_part[16][NC];
     __shared__ double s_red[2 * (WG / 64)];
     __shared__ double s_lt[TAMCMC_MAX_HARVEY];  // FAST: ln(1e-3*tau_k)
 
@@ -239,6 +261,15 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     if (FAST) {
         if (tid < nh) s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
     }
+    // tile geometry for the far field: centre and half-width of the nominal tile on the regular grid
+    const double h = 0.5 * (double)TILE * a.step;
+    const double xc = a.x0 + ((double)t0 + 0.5 * (double)TILE - 0.5) * a.step;
+    double fcoef[NC];
+    if (FARFIELD) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) fcoef[k] = 0.0;
+        if (tid == 0) s_anyfar = 0;
+    }
 
     const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
     for (int c0 = mbeg; c0 < mend; c0 += CHUNK) {
@@ -252,8 +283,21 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 i1 = a.mults[idx].i1;
                 ov = (i0 < t1) && (i1 > t0);
             }
-            const unsigned long long mask = __ballot(ov);
-            if (ov) {
+            bool far = false;
+            if (FARFIELD && ov && i0 <= t0 && i1 >= t1) {
+                const tamcmc_multiplet &g = a.mults[idx];
+                const double ig = 2.0 / g.gamma, beta = ig * h;
+                far = true;
+                for (int m = 0; m < 2 * g.l + 1; m++) {
+                    const double A = ig * (g.nu[m] - xc);
+                    const double q2 = beta * beta / fma(A, A, 1.0);
+                    if (!(q2 <= RHO_MAX2)) far = false;  // also rejects NaN
+                }
+            }
+            const unsigned long long fmask = __ballot(far);
+            const unsigned long long mask = __ballot(ov && !far);
+            if (far) s_far[__popcll(fmask & ((1ull << tid) - 1ull))] = idx;
+            if (ov && !far) {
                 const int pos = __popcll(mask & ((1ull << tid) - 1ull));
                 const tamcmc_multiplet &g = a.mults[idx];
                 LdsMult &d = s_m[pos];
@@ -284,10 +328,45 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 7; m++) d.nh[m] = make_double2(g.nu[m], g.hv[m]);
             }
+            if (tid == 0) {
+                s_nfar = __popcll(fmask);
+                if (fmask) s_anyfar = 1;
+            }
             if (tid == 0) s_n = __popcll(mask);
         }
         __syncthreads();
         const int n = s_n;
+        if (FARFIELD) {
+            // one lane per (far multiplet, m) slot: its NC Taylor coefficients, accumulated in registers
+            const int nslots = s_nfar * 7;
+            for (int slot = tid; slot < nslots; slot += WG) {
+                const int jf = slot / 7, mm = slot - jf * 7;
+                const tamcmc_multiplet &g = a.mults[s_far[jf]];
+                if (mm < 2 * g.l + 1) {
+                    const double ig = 2.0 / g.gamma, beta = ig * h;
+                    const double A = ig * (g.nu[mm] - xc);
+                    const double inv = rcp_nr2(fma(A, A, 1.0));
+                    const double two_req = 2.0 * beta * A * inv, q2 = beta * beta * inv;
+                    double c[NC];
+                    c[0] = g.hv[mm] * inv;
+                    c[1] = c[0] * two_req;
+#pragma unroll
+                    for (int k = 1; k < NC - 1; k++) c[k + 1] = fma(two_req, c[k], -q2 * c[k - 1]);
+                    if (g.asym != 0.0) {
+                        // times the asymmetry factor (1+asym(x/nu_c-1))^2 + c2^2 = A0 + A1 s + A2 s^2
+                        const double p0 = fma(g.asym, xc / g.fc - 1.0, 1.0), p1 = g.asym * h / g.fc;
+                        const double c2 = 0.5 * g.gamma * g.asym / g.fc;
+                        const double A0 = fma(p0, p0, c2 * c2), A1 = 2.0 * p0 * p1, A2 = p1 * p1;
+#pragma unroll
+                        for (int k = NC - 1; k >= 2; k--) c[k] = fma(A0, c[k], fma(A1, c[k - 1], A2 * c[k - 2]));
+                        c[1] = fma(A0, c[1], A1 * c[0]);
+                        c[0] = A0 * c[0];
+                    }
+#pragma unroll
+                    for (int k = 0; k < NC; k++) fcoef[k] = fcoef[k] + c[k];
+                }
+            }
+        }
         for (int q = 0; q < n; q++) {
             const LdsMult &M = s_m[q];
             switch (M.l) {  // wave-uniform
@@ -298,7 +377,39 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
             }
         }
     }
-    if (FAST) __syncthreads();  // s_lt visible (also when the evaluation has no multiplet chunk)
+    if (FAST) __syncthreads();  // s_lt visible (also when the evaluation has no multiplet chunk); near list consumed
+    if (FARFIELD) {
+        if (s_anyfar) {  // workgroup-uniform
+            // deterministic two-level sum of the 256 per-lane coefficient vectors (rows alias the near list)
+#pragma unroll
+            for (int k = 0; k < NC; k += 2) *(double2 *)&s_rows[tid * ROW + k] = make_double2(fcoef[k], fcoef[k + 1]);
+            __syncthreads();
+            {
+                const int k = tid & 15, part = tid >> 4;
+                double sum = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) sum = sum + s_rows[(part * 16 + r) * ROW + k];
+                s_part[part][k] = sum;
+            }
+            __syncthreads();
+            if (tid < NC) {
+                double sum = 0.0;
+#pragma unroll
+                for (int p = 0; p < 16; p++) sum = sum + s_part[p][tid];
+                s_coef[tid] = sum;
+            }
+            __syncthreads();
+            const double inv_h = 1.0 / h;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const double sx = (xv[k] - xc) * inv_h;
+                double P = s_coef[NC - 1];
+#pragma unroll
+                for (int q = NC - 2; q >= 0; q--) P = fma(P, sx, s_coef[q]);
+                acc[k] = acc[k] + P;
+            }
+        }
+    }
 
     // ---- background + likelihood terms ----
     double s[2] = {0.0, 0.0};
@@ -377,31 +488,35 @@ __global__ void __launch_bounds__(WG) k_finalize(const double *partials, int nti
     if (threadIdx.x == 0) S[b] = out[0] + out[1];
 }
 
-template <bool FAST, int K>
+template <int MODE, int K>
 void launch_k(const LoglikeArgs &a, bool write_model, int grid, hipStream_t st) {
-    if (write_model) hipLaunchKernelGGL((k_loglike<FAST, K, true>), dim3(grid), dim3(WG), 0, st, a);
-    else hipLaunchKernelGGL((k_loglike<FAST, K, false>), dim3(grid), dim3(WG), 0, st, a);
+    if (write_model) hipLaunchKernelGGL((k_loglike<MODE, K, true>), dim3(grid), dim3(WG), 0, st, a);
+    else hipLaunchKernelGGL((k_loglike<MODE, K, false>), dim3(grid), dim3(WG), 0, st, a);
 }
 
 }  // namespace
 
 int tile_bins(int K) { return WG * K; }
 
-hipError_t launch_loglike(LoglikeArgs a, bool fast, int K, bool write_model, hipStream_t st) {
+hipError_t launch_loglike(LoglikeArgs a, int mode, int K, bool write_model, hipStream_t st) {
     if (a.B <= 0) return hipSuccess;
     const int tb = WG * K;
     a.ntiles = (a.Nx + tb - 1) / tb;
     const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
     const long long grid = (long long)ntiles_pad * a.B;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (fast) {
-        if (K == 1) launch_k<true, 1>(a, write_model, (int)grid, st);
-        else if (K == 2) launch_k<true, 2>(a, write_model, (int)grid, st);
-        else launch_k<true, 4>(a, write_model, (int)grid, st);
+    if (mode == M_FAST) {
+        if (K == 1) launch_k<M_FAST, 1>(a, write_model, (int)grid, st);
+        else if (K == 2) launch_k<M_FAST, 2>(a, write_model, (int)grid, st);
+        else launch_k<M_FAST, 4>(a, write_model, (int)grid, st);
+    } else if (mode == M_FAST_DIRECT) {
+        if (K == 1) launch_k<M_FAST_DIRECT, 1>(a, write_model, (int)grid, st);
+        else if (K == 2) launch_k<M_FAST_DIRECT, 2>(a, write_model, (int)grid, st);
+        else launch_k<M_FAST_DIRECT, 4>(a, write_model, (int)grid, st);
     } else {
-        if (K == 1) launch_k<false, 1>(a, write_model, (int)grid, st);
-        else if (K == 2) launch_k<false, 2>(a, write_model, (int)grid, st);
-        else launch_k<false, 4>(a, write_model, (int)grid, st);
+        if (K == 1) launch_k<M_STRICT, 1>(a, write_model, (int)grid, st);
+        else if (K == 2) launch_k<M_STRICT, 2>(a, write_model, (int)grid, st);
+        else launch_k<M_STRICT, 4>(a, write_model, (int)grid, st);
     }
     return hipGetLastError();
 }

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ctxs(pkg):
-    c = {"strict": pkg.HipContext(0, precision=pkg.PRECISION_STRICT), "fast": pkg.HipContext(0, precision=pkg.PRECISION_FAST)}
+    c = {"strict": pkg.HipContext(0, precision=pkg.PRECISION_STRICT), "fast": pkg.HipContext(0, precision=pkg.PRECISION_FAST),
+         "fast_direct": pkg.HipContext(0, precision=pkg.PRECISION_FAST_DIRECT)}
     yield c
     for v in c.values():
         v.close()
@@ -51,13 +52,14 @@ def test_reference_recipe_strict_bit_exact(pkg, oracle, synth, ctxs, seed, K):
     ref = oracle.chi22p_ld(y, m_o, 1)
     assert abs(logL[0] - ref) <= 1e-12 * abs(ref)
     assert np.linalg.norm(model[0] - m_o) <= 1e-8
-    f = ctxs["fast"]
-    f.set_option(pkg.OPT_BINS_PER_THREAD, K)
-    f.set_spectrum(x, y)
-    logLf, modelf, _ = f.loglike_params_batch(23, p, pl, want_model=True)
-    assert np.max(np.abs(modelf[0] - m_o) / m_o) <= 1e-12
-    assert abs(logLf[0] - ref) <= 1e-11 * abs(ref)
-    assert np.linalg.norm(modelf[0] - m_o) <= 1e-12 * np.linalg.norm(m_o)
+    for name in ("fast", "fast_direct"):
+        f = ctxs[name]
+        f.set_option(pkg.OPT_BINS_PER_THREAD, K)
+        f.set_spectrum(x, y)
+        logLf, modelf, _ = f.loglike_params_batch(23, p, pl, want_model=True)
+        assert np.max(np.abs(modelf[0] - m_o) / m_o) <= 1e-12, name
+        assert abs(logLf[0] - ref) <= 1e-11 * abs(ref), name
+        assert np.linalg.norm(modelf[0] - m_o) <= 1e-12 * np.linalg.norm(m_o), name
 
 
 def test_c2_local_batch_tempered(pkg, oracle, synth, ctxs):
@@ -68,7 +70,7 @@ def test_c2_local_batch_tempered(pkg, oracle, synth, ctxs):
     P = _perturbed(star, B, rng)
     T = 1.7 ** np.arange(B)
     ref, m_o, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T, want_model=True)
-    for name, tol_m, tol_l in (("strict", 0.0, 1e-12), ("fast", 1e-12, 1e-11)):
+    for name, tol_m, tol_l in (("strict", 0.0, 1e-12), ("fast", 1e-12, 1e-11), ("fast_direct", 1e-12, 1e-11)):
         c = ctxs[name]
         c.set_option(pkg.OPT_BINS_PER_THREAD, 2)
         c.set_spectrum(star.x, y)
@@ -93,7 +95,7 @@ def test_c3_like_global_with_harvey_and_asymmetry(pkg, oracle, synth, ctxs):
     T = 1.4 ** np.arange(B)
     ref, m_o, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T, want_model=True)
     assert (st_o == 0).all()
-    for name, tol_m, tol_l in (("strict", 1e-15, 1e-12), ("fast", 1e-12, 1e-11)):
+    for name, tol_m, tol_l in (("strict", 1e-15, 1e-12), ("fast", 1e-12, 1e-11), ("fast_direct", 1e-12, 1e-11)):
         c = ctxs[name]
         c.set_spectrum(star.x, y)
         logL, model, status = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0, want_model=True)
@@ -182,7 +184,7 @@ def test_full_size_c3_properties(pkg, oracle, synth, ctxs):
     T = 1.35 ** np.arange(B)
     ref, _, _ = oracle.loglike_batch(star.model_id, P[:2], star.plength, star.x, y, 1.0, T[:2])
     out = {}
-    for name in ("strict", "fast"):
+    for name in ("strict", "fast", "fast_direct"):
         c = ctxs[name]
         c.set_option(pkg.OPT_BINS_PER_THREAD, 2)
         c.set_spectrum(star.x, y)
@@ -196,6 +198,7 @@ def test_full_size_c3_properties(pkg, oracle, synth, ctxs):
         assert np.array_equal(again, logL)
         out[name] = logL
     assert np.max(np.abs(out["fast"] - out["strict"]) / np.abs(out["strict"])) <= 1e-11
+    assert np.max(np.abs(out["fast_direct"] - out["strict"]) / np.abs(out["strict"])) <= 1e-11
     P0 = star.params.copy()
     P0[:14] = 0.0
     c = ctxs["strict"]
