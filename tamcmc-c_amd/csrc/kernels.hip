@@ -46,7 +46,11 @@ constexpr int M_STRICT = 0, M_FAST_DIRECT = 2, M_FAST = 1;
 // Component: hv/(1+(beta s - A)^2) = sum_k c_k s^k, c_k = -hv Im(u q^k), u = 1/(A+i), q = beta u, |q| = rho, with the
 // three-term recurrence c_{k+1} = 2 Re(q) c_k - |q|^2 c_{k-1}.  Truncation error <= rho^NC/(1-rho) of the (small) far term.
 constexpr int NC = 16;
-constexpr double RHO_MAX2 = 0.125 * 0.125;  // rho <= 1/8  ->  8^-16 = 3.6e-15
+constexpr double RHO_MAX2 = 1.0 / 36.0;  // rho <= 1/6 -> truncation <= 6^-16/(1-1/6) = 4e-13 of the far term (itself <~ 0.3 M)
+constexpr double RHO_MAX2_ASYM = 1.0 / 64.0;  // asymmetric profiles: the far wing can dominate M and the quadratic
+                                              // factor feeds degree >= NC terms back -> rho <= 1/8 (3.6e-15)
+constexpr int NH = 8;                    // Taylor coefficients of a Harvey term on a tile (x_c >> h)
+constexpr double EPS_MAX = 0.02;         // ... used when h/x_c <= EPS_MAX: truncation ~ C(p,8) 0.02^8 = 2.6e-14
 constexpr int ROW = NC + 2;  // LDS row stride of the coefficient reduction (16-byte aligned, conflict-free b128 writes)
 
 // LDS image of a multiplet (160 B, every field group 16-byte aligned for ds_read_b128).
@@ -265,10 +269,37 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     const double h = 0.5 * (double)TILE * a.step;
     const double xc = a.x0 + ((double)t0 + 0.5 * (double)TILE - 0.5) * a.step;
     double fcoef[NC];
+    // FARFIELD: the background H/(1+(a x)^p) + N0 is analytic on the tile with its singularities ~x_c away, so it joins the
+    // tile polynomial: u(s) = (a x_c)^p (1+eps s)^p (binomial series), then the reciprocal series of 1+u.
+    const bool harvey_poly = FARFIELD && (fabs(h) <= EPS_MAX * fabs(xc)) && (xc > 0.0);
     if (FARFIELD) {
 #pragma unroll
         for (int k = 0; k < NC; k++) fcoef[k] = 0.0;
-        if (tid == 0) s_anyfar = 0;
+        if (tid == 0) s_anyfar = harvey_poly ? 1 : 0;
+        if (harvey_poly) {
+            if (tid < nh) {  // lane = Harvey term; its NH coefficients go to fcoef[0..NH) of that lane
+                const double Hh = nz[3 * tid], tau = nz[3 * tid + 1], pw = nz[3 * tid + 2];
+                if (tau != 0.0) {
+                    const double eps = h / xc;
+                    double u[NH], f[NH];
+                    u[0] = exp(pw * log(1e-3 * tau * xc));
+#pragma unroll
+                    for (int k = 0; k < NH - 1; k++) u[k + 1] = u[k] * eps * (pw - (double)k) / (double)(k + 1);
+                    const double iv0 = 1.0 / (1.0 + u[0]);
+                    f[0] = Hh * iv0;
+#pragma unroll
+                    for (int k = 1; k < NH; k++) {
+                        double acc2 = 0.0;
+#pragma unroll
+                        for (int jj = 1; jj <= k; jj++) acc2 = fma(u[jj], f[k - jj], acc2);
+                        f[k] = -acc2 * iv0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NH; k++) fcoef[k] = f[k];
+                }
+            }
+            if (tid == TAMCMC_MAX_HARVEY) fcoef[0] = nz[nn - 1];  // white noise joins the constant term
+        }
     }
 
     const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
@@ -286,12 +317,12 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
             bool far = false;
             if (FARFIELD && ov && i0 <= t0 && i1 >= t1) {
                 const tamcmc_multiplet &g = a.mults[idx];
-                const double ig = 2.0 / g.gamma, beta = ig * h;
+                const double ig = 2.0 * rcp_nr2(g.gamma), beta2 = (ig * h) * (ig * h);
+                const double r2 = (g.asym != 0.0) ? RHO_MAX2_ASYM : RHO_MAX2;
                 far = true;
                 for (int m = 0; m < 2 * g.l + 1; m++) {
                     const double A = ig * (g.nu[m] - xc);
-                    const double q2 = beta * beta / fma(A, A, 1.0);
-                    if (!(q2 <= RHO_MAX2)) far = false;  // also rejects NaN
+                    if (!(beta2 <= r2 * fma(A, A, 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
                 }
             }
             const unsigned long long fmask = __ballot(far);
@@ -309,17 +340,17 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 d.c2sq = c2 * c2;
                 d.asym = g.asym;
                 if (FAST) {
-                    const double ig = 2.0 / g.gamma;
+                    const double ig = 2.0 * rcp_nr2(g.gamma);
                     d.g = ig;
                     d.fcx = g.asym / g.fc;
-                    // bound of prod_m (1 + ((x-nu_m) ig)^2) over the tile
+                    // prod_m (1 + ((x-nu_m) ig)^2) < (1e38)^7 = 1e266 on the whole tile?
                     const double xlo = a.x[t0], xhi = a.x[t1 - 1];
-                    double lg = 0.0;
+                    bool safe = true;
                     for (int m = 0; m < 2 * l + 1; m++) {
                         const double dm = fmax(fabs(xlo - g.nu[m]), fabs(xhi - g.nu[m])) * ig;
-                        lg += log2(fma(dm, dm, 1.0));
+                        if (!(fma(dm, dm, 1.0) < 1e38)) safe = false;  // also false for NaN/inf inputs
                     }
-                    if (lg < 900.0) flags |= F_SAFE;  // also false for NaN/inf inputs
+                    if (safe) flags |= F_SAFE;
                 } else {
                     d.g = g.gamma * g.gamma;
                     d.fcx = g.fc;
@@ -343,7 +374,7 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 const int jf = slot / 7, mm = slot - jf * 7;
                 const tamcmc_multiplet &g = a.mults[s_far[jf]];
                 if (mm < 2 * g.l + 1) {
-                    const double ig = 2.0 / g.gamma, beta = ig * h;
+                    const double ig = 2.0 * rcp_nr2(g.gamma), beta = ig * h;
                     const double A = ig * (g.nu[mm] - xc);
                     const double inv = rcp_nr2(fma(A, A, 1.0));
                     const double two_req = 2.0 * beta * A * inv, q2 = beta * beta * inv;
@@ -422,11 +453,11 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
         const int bi = min(bin[k], a.Nx - 1);
         const bool valid = bin[k] < a.Nx;
         if (!FAST) {
-            for (int h = 0; h < nh; h++) {
-                const double tau = nz[3 * h + 1];
+            for (int hh = 0; hh < nh; hh++) {
+                const double tau = nz[3 * hh + 1];
                 if (tau != 0.0) {
-                    double t = pow((1e-3 * tau) * xv[k], nz[3 * h + 2]);
-                    t = nz[3 * h] * (1.0 / (t + 1.0));
+                    double t = pow((1e-3 * tau) * xv[k], nz[3 * hh + 2]);
+                    t = nz[3 * hh] * (1.0 / (t + 1.0));
                     Mv = Mv + t;
                 }
             }
@@ -436,15 +467,17 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 s[1] = s[1] + log(Mv);
             }
         } else {
-            const double lx = a.logx[bi];
-            for (int h = 0; h < nh; h++) {
-                const double tau = nz[3 * h + 1];
-                if (tau != 0.0) {
-                    const double t = exp(nz[3 * h + 2] * (s_lt[h] + lx));
-                    Mv = fma(nz[3 * h], rcp_nr2(t + 1.0), Mv);
+            if (!harvey_poly) {
+                const double lx = a.logx[bi];
+                for (int hh = 0; hh < nh; hh++) {
+                    const double tau = nz[3 * hh + 1];
+                    if (tau != 0.0) {
+                        const double t = exp(nz[3 * hh + 2] * (s_lt[hh] + lx));
+                        Mv = fma(nz[3 * hh], rcp_nr2(t + 1.0), Mv);
+                    }
                 }
+                Mv = Mv + white;
             }
-            Mv = Mv + white;
             if (valid) {
                 s[0] = fma(a.y[bi], rcp_nr2(Mv), s[0]);
                 prod = prod * Mv;
