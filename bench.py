@@ -73,6 +73,15 @@ def cpu_baseline(star, y, nchains, lam, budget_s):
                       "hot path only (no proposal/Cholesky/output cost), so it flatters the CPU"}
 
 
+def pmc_traffic():
+    """HBM bytes per k_loglike launch from the committed PMC passes (None if no profile has been committed)."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return json.load(open(p))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -106,28 +115,16 @@ def main():
         return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=eng,
                            Nt_learn=(max(learn_until // 2, 1), max(learn_until, 2)), periods_learn=(1,), dN_mixing=1)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    from tamcmc_c_amd import shard
     smp = make_sampler(1 if a.sampler == "mala" else 0, a.warmup)
     smp.run(a.warmup, record=False)
     ctx.reset_kernel_stats()
     acc0 = smp.state()
-    barrier()
-    t0 = time.perf_counter()
-    smp.run(a.steps, record=False)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # barrier + synchronize on both sides, MAX over ranks (tests/test_multirank_gloo.py covers this on gloo)
+    elapsed, _ = shard.timed_region(lambda: smp.run(a.steps, record=False), dist=dist, sync=torch.cuda.synchronize)
     k_ms, k_launches, k_evals = ctx.kernel_stats()
     st = smp.state()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = world * a.steps / elapsed
+    value = shard.aggregate_rate(a.steps, world, elapsed)
 
     extra = {}
     if a.mala_steps > 0 and a.sampler == "mh" and world == 1:
@@ -165,11 +162,15 @@ def main():
                                   if (a.engine == "device" and a.sampler == "mh") else "host-driven loop"),
                        "arithmetic": a.precision, "component_bin_evals_per_model": W},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_loglike",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(), "traffic_unit": "bytes per launch",
+                         "traffic_source": "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                           "passes, FETCH_SIZE x2 (gfx950), same 20-evaluation launch; not re-measured live",
+                         "kernel": "k_loglike",
                          "kernel_us_per_launch": k_s * 1e6, "evaluations_per_launch": evals_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "fp64_valu": {"component_evals_per_s": W * evals_per_launch / k_s,
-                                       "note": "the path is fp64-VALU(divide)-bound: ~80-110 component evaluations per 16 B"}},
+                                       "note": "the path is fp64-VALU-bound (~110 Lorentzian components per 16 B); FAST mode folds far "
+                                               "components into one polynomial per tile, so this is an EFFECTIVE rate"}},
             "accept_rate_chain0": (st["accepted0"] - acc0["accepted0"]) / max(a.steps, 1),
             "swap_rate": st["swaps"] / max(st["swap_attempts"], 1),
             "kernel_time_fraction": k_ms * 1e-3 / elapsed,

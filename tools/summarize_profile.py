@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries under profiles/."""
+import csv, glob, json, os, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+lines = [f"# rocprofv3 summary {tag} (MI355X, one GPU)", ""]
+ks = glob.glob(f"{src}/trace/*/*kernel_stats.csv")
+if ks:
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --mala-steps 0`", "",
+              "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(ks[0])):
+        lines.append(f"| `{r['Name'][:110]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.2f} | "
+                     f"{float(r['Percentage']):.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} |")
+    lines.append("")
+try:
+    b = json.loads(open(f"{src}/bench.json").read())
+    lines += ["## bench.py line of the same build (un-profiled run)", "", "```json", json.dumps(b, indent=1), "```", ""]
+except Exception as e:
+    lines += [f"(no bench.json: {e})", ""]
+agg = collections.defaultdict(list)
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+    for f in glob.glob(f"{src}/{d}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "k_loglike<1, 4, false>" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+if agg:
+    lines += ["## PMC, kernel `k_loglike<FAST, K=4>` , 20-evaluation launch (C3), mean over 10 launches, separate passes", "",
+              "| counter | mean per launch |", "|---|---|"]
+    for k in sorted(agg):
+        lines.append(f"| {k} | {sum(agg[k])/len(agg[k]):.4g} |")
+    fetch = sum(agg["FETCH_SIZE"]) / len(agg["FETCH_SIZE"]) if agg.get("FETCH_SIZE") else None
+    write = sum(agg["WRITE_SIZE"]) / len(agg["WRITE_SIZE"]) if agg.get("WRITE_SIZE") else None
+    if fetch is not None and write is not None:
+        hbm = (2.0 * fetch + write) * 1024.0   # FETCH_SIZE/WRITE_SIZE are in KB; gfx950: FETCH_SIZE reads 1/2 of a wide stream
+        lines += ["", f"HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB = **{hbm/1e6:.2f} MB** "
+                      f"(algorithmic bytes of the launch: 16 B x 1e5 bins x 20 evaluations = 32 MB; the spectrum is served from L2)."]
+        json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write, "correction": "FETCH_SIZE x2 (gfx950)",
+                   "launch": "k_loglike FAST K=4, B=20, Nx=1e5"}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(lines) + "\n")
+for f in ks:
+    import shutil
+    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+print("\n".join(lines[:40]))
