@@ -119,6 +119,17 @@ int tamcmc_hip_fd_gradient(tamcmc_hip_ctx *ctx, int model_id, int C, const doubl
                            const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep,
                            const double *Tcoefs, double p, double *logL0, double *grad);
 
+/* Same batch, gradient of the tempered log-POSTERIOR: each of the C*(Nvars+1) workgroups also evaluates the log-prior of
+ * its perturbed vector on the device (prior_class 2 = io_MS_Global, 3 = io_local; priors = 4 x Nparams row-major table,
+ * priors_switch = primitive ids, extra_priors[10]: Input_Data of tamcmc/headers/data.h:51-62).  Where the forward point
+ * leaves a prior's support the backward difference of the prior is used, else that prior term is flat.
+ * Out: logL0[C] (tempered), logPr0[C] (may be NULL), grad[C x Nvars]. */
+int tamcmc_hip_fd_gradient_posterior(tamcmc_hip_ctx *ctx, int model_id, int prior_class, int C, const double *params,
+                                     int64_t Nparams, const int32_t *plength, const int32_t *index_to_relax, int Nvars,
+                                     const double *hstep, const double *Tcoefs, double p, const double *priors,
+                                     const int32_t *priors_switch, const double *extra_priors, double *logL0, double *logPr0,
+                                     double *grad);
+
 /* Timing of the likelihood kernel measured with HIP events on the context's own stream
  * (enabled by TAMCMC_OPT_TIMING): totals since the last reset. */
 int tamcmc_hip_get_kernel_stats(tamcmc_hip_ctx *ctx, double *kernel_ms_total, int64_t *launches,

@@ -46,6 +46,7 @@ void tamcmc_hip_destroy(tamcmc_hip_ctx *c) {
     c->dx.release(); c->dy.release(); c->dlogx.release();
     c->h_stage.release(); c->d_stage.release();
     c->d_part.release(); c->d_S.release(); c->d_model.release(); c->h_S.release();
+    c->d_fd.release(); c->d_poly.release(); c->h_fd.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -232,43 +233,6 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, cons
     for (int b = 0; b < B; b++)
         if (status[b] != TAMCMC_OK) logL[b] = NAN;
     return first_err;
-}
-
-int tamcmc_hip_fd_gradient(tamcmc_hip_ctx *c, int model_id, int C, const double *params, int64_t Nparams,
-                           const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep,
-                           const double *Tcoefs, double p, double *logL0, double *grad) {
-    if (!c) return TAMCMC_ERR_BAD_ARG;
-    if (C < 0 || Nvars < 0 || !params || !plength || !index_to_relax || !hstep || !logL0 || !grad) return TAMCMC_ERR_BAD_ARG;
-    if (C == 0) return TAMCMC_OK;
-    for (int k = 0; k < Nvars; k++)
-        if (index_to_relax[k] < 0 || index_to_relax[k] >= Nparams) return TAMCMC_ERR_BAD_ARG;
-    const int E = Nvars + 1;
-    std::vector<double> P((size_t)C * E * Nparams), T((size_t)C * E), L((size_t)C * E), happ((size_t)C * Nvars);
-    for (int ch = 0; ch < C; ch++) {
-        const double *src = params + (size_t)ch * Nparams;
-        for (int e = 0; e < E; e++) {
-            double *dst = P.data() + ((size_t)ch * E + e) * Nparams;
-            std::memcpy(dst, src, (size_t)Nparams * sizeof(double));
-            T[(size_t)ch * E + e] = Tcoefs ? Tcoefs[ch] : 1.0;
-            if (e > 0) {
-                const int i = index_to_relax[e - 1];
-                volatile double xp = src[i] + hstep[e - 1];
-                dst[i] = xp;
-                happ[(size_t)ch * Nvars + e - 1] = xp - src[i];  // the step actually applied
-            }
-        }
-    }
-    std::vector<int32_t> status((size_t)C * E);
-    int rc = tamcmc_hip_loglike_params_batch(c, model_id, C * E, P.data(), Nparams, plength, T.data(), p, L.data(),
-                                             nullptr, status.data());
-    if (rc == TAMCMC_ERR_HIP || rc == TAMCMC_ERR_BAD_ARG || rc == TAMCMC_ERR_BAD_MODEL || rc == TAMCMC_ERR_NO_SPECTRUM)
-        return rc;
-    for (int ch = 0; ch < C; ch++) {
-        logL0[ch] = L[(size_t)ch * E];
-        for (int k = 0; k < Nvars; k++)
-            grad[(size_t)ch * Nvars + k] = (L[(size_t)ch * E + k + 1] - L[(size_t)ch * E]) / happ[(size_t)ch * Nvars + k];
-    }
-    return rc;
 }
 
 int tamcmc_hip_get_kernel_stats(tamcmc_hip_ctx *c, double *kernel_ms_total, int64_t *launches, int64_t *evaluations) {

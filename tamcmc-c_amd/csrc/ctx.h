@@ -71,6 +71,10 @@ struct tamcmc_hip_ctx {
     tamcmc::PinBuf<unsigned char> h_stage;
     tamcmc::DevBuf<unsigned char> d_stage;
     tamcmc::DevBuf<double> d_part, d_S, d_model;
+    // finite-difference batches built on the device (fd_batch.hip)
+    tamcmc::DevBuf<unsigned char> d_fd, d_poly;
+    tamcmc::PinBuf<unsigned char> h_fd;
+    bool poly_ready = false;
     tamcmc::PinBuf<double> h_S;
     // stats
     double kernel_ms = 0;

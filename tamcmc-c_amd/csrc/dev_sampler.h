@@ -3,23 +3,25 @@
 #include <stdint.h>
 
 #include "../../include/tamcmc_hip.h"
+#if defined(__HIPCC__)
+#include "dev_unpack.h"
+#endif
 
 #define TAMCMC_MAX_CHAINS 64  // the reference caps at 24 (MALA.cpp:580-587); BASELINE config 5 asks for 40
 
 namespace tamcmc {
 
+#if defined(__HIPCC__)
 // Kernel argument block: device pointers + scalars (passed by value).
 struct DevSamplerArgs {
-    int model_id, prior_class, C, Np, Nv, per, stride, Nx, ntiles, chol_in_lds;
+    ModelDesc desc;       // model_id, prior_class, Np, per, stride, Nx, grid, plength/priors/extra/poly pointers
+    int C, Nv, ntiles, chol_in_lds;
     long pl;              // likelihood_params truncated to long (likelihoods.h:14)
     long dN_mixing;
     uint64_t seed;
-    double x_first, x_last, step;
     double c0, epsilon1, epsi2, A1, target_acceptance;
-    // model description (constant)
-    const int *plength, *index_to_relax, *priors_switch;
-    const double *priors, *extra, *Tcoefs;
-    const void *poly;     // mt::PolyTab (Pslm/Qlm tables) in device memory
+    const int *index_to_relax;
+    const double *Tcoefs;
     // chain state
     double *vars_cur, *params_cur, *logL_cur, *logPr_cur, *logPost_cur, *init_logL;
     double *vars_prop, *params_prop, *logPr_prop;
@@ -37,6 +39,7 @@ struct DevSamplerArgs {
     // records
     double *samples, *stats;
 };
+#endif
 
 struct DevSamplerInit {
     int model_id, prior_class, C, Np, Nv;

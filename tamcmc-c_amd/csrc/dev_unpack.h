@@ -1,0 +1,181 @@
+// dev_unpack.h -- device-side (workgroup-cooperative) log-prior and params -> multiplet-table unpack,
+// shared by the device-resident sampler (dev_sampler.hip) and the finite-difference batch builder (capi.hip).
+// The arithmetic itself is mode_tables_impl.h / priors_impl.h (written once for host and device); this file only
+// spreads it over the lanes of one workgroup: prior terms one per lane (tree-summed), hard constraints sliced over the
+// lanes, one lane per Wigner term / element, one lane per multiplet.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mode_tables_impl.h"
+#include "priors_impl.h"
+
+namespace tamcmc {
+
+struct ModelDesc {  // constant description of one star's model (device pointers)
+    int model_id, prior_class, Np, per, stride, Nx;
+    double x_first, x_last, step;
+    const int *plength, *priors_switch;
+    const double *priors, *extra;
+    const void *poly;  // mt::PolyTab in device memory
+};
+
+struct TablePtrs {  // the likelihood kernel's input block
+    tamcmc_multiplet *mults;
+    int *pairs, *nh, *nn;
+    double *noise;
+};
+
+// LDS scratch of the cooperative routines: 8 + 40 doubles, a PolyTab, a Shared, 4 ints/doubles
+struct UnpackLds {
+    double *red;        // [8]
+    double *w;          // [40] Wigner terms (0..27) and elements (28..39)
+    mt::PolyTab *poly;
+    mt::Shared *S;
+    int *status, *reject;
+    double *dnu;
+};
+__host__ __device__ inline size_t unpack_lds_bytes() {
+    return (8 + 40) * sizeof(double) + sizeof(mt::PolyTab) + sizeof(mt::Shared) + 64;
+}
+__device__ inline UnpackLds carve_unpack_lds(unsigned char *p) {
+    UnpackLds u;
+    u.red = (double *)p;
+    u.w = u.red + 8;
+    u.poly = (mt::PolyTab *)(u.w + 40);
+    u.S = (mt::Shared *)(u.poly + 1);
+    u.dnu = (double *)(((uintptr_t)(u.S + 1) + 7) & ~(uintptr_t)7);
+    u.status = (int *)(u.dnu + 1);
+    u.reject = u.status + 1;
+    return u;
+}
+
+__device__ __forceinline__ double wg_sum(double v, double *s_red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off, 64);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    double s = s_red[0];
+    for (int w = 1; w < nw; w++) s = s + s_red[w];
+    __syncthreads();
+    return s;
+}
+
+// Call once per workgroup before the routines below (ends with a barrier).
+__device__ inline void unpack_begin(const ModelDesc &d, const UnpackLds &u) {
+    const double *src = (const double *)d.poly;
+    double *dst = (double *)u.poly;
+    for (int i = threadIdx.x; i < (int)(sizeof(mt::PolyTab) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x == 0) { *u.status = TAMCMC_OK; *u.reject = 0; }
+    __syncthreads();
+}
+
+// log-prior of the parameter vector in LDS (call_prior, model_def.cpp:421-464): returns the same value in every lane.
+// While the additive terms are summed, the LAST lane prepares the unpack's shared scalars (different wave: overlaps).
+__device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, bool prepare_unpack) {
+    const int tid = threadIdx.x, nt = blockDim.x, Np = d.Np;
+    {
+        int st = TAMCMC_OK;
+        mt::xreal c = 0;
+        if (d.prior_class == 2) {
+            c = pr::ms_global_constraints(s_params, d.plength, d.priors_switch, d.extra, &st, tid, nt);
+            if (tid == 1) {
+                double fit[2];
+                mt::linfit_index(s_params + d.plength[0] + d.plength[1], d.plength[2], fit);
+                *u.dnu = fit[0];
+            }
+        } else if (d.prior_class == 3) {
+            if (tid == 0) c = pr::local_constraints(s_params, d.plength, d.priors_switch, d.extra);
+        } else {
+            c = pr::neg_inf();
+            st = TAMCMC_ERR_BAD_MODEL;
+        }
+        if (c != 0) *u.reject = 1;
+        if (st != TAMCMC_OK) *u.status = st;
+    }
+    __syncthreads();
+    const int n_extra = (d.prior_class == 2) ? pr::ms_global_extra_terms(d.plength, d.extra) : 0;
+    double f = 0;
+    int st = TAMCMC_OK;
+    for (int t = tid; t < Np + n_extra; t += nt) {
+        if (t < Np) f = f + pr::generic_prior_term(s_params, Np, d.priors, d.priors_switch, t, &st);
+        else f = f + pr::ms_global_extra_term(s_params, d.plength, d.extra, *u.dnu, t - Np);
+    }
+    if (st != TAMCMC_OK) *u.status = st;
+    if (prepare_unpack && tid == nt - 1) mt::shared_scalars_base(d.model_id, s_params, d.plength, *u.S);
+    f = wg_sum(f, u.red);
+    return *u.reject ? -INFINITY : f;
+}
+
+// params (LDS) -> table rows of evaluation slot `slot` (+ noise row, range, counts).  `live` = the prior is finite
+// (model_def.cpp:472,476-480 skips the model otherwise).  u.S must hold shared_scalars_base (wg_log_prior did it).
+__device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, const UnpackLds &u, int slot, const TablePtrs &T,
+                                 bool live) {
+    const int tid = threadIdx.x, nt = blockDim.x, per = d.per;
+    mt::Shared *S = u.S;
+    if (live) {
+        // m-visibilities (function_rot.cpp): one lane per TERM of each Wigner sum d^l_{i,0}(beta), i=0..l, and of the centre
+        // elements d^l_{0,0}(-beta); slot layout: for l=1..3, for i=0..l, then the centre (i=0, -beta): terms s=0..l-i (28).
+        // Each lane first FINDS its (l, i, s), then all lanes evaluate their term together (no divergent calls).
+        {
+            const double PI = 3.141592653589793238462643;
+            const double ang = PI * S->inc / 180.;
+            int sl = 0, my_l = 0, my_i = 0, my_s = 0;
+            double my_b = 0;
+            for (int l = 1; l <= 3; l++)
+                for (int e = 0; e <= l + 1; e++) {
+                    const int i = (e <= l) ? e : 0;
+                    for (int s = 0; s <= l - i; s++, sl++)
+                        if (sl == tid) { my_l = l; my_i = i; my_s = s; my_b = (e <= l) ? ang : -ang; }
+                }
+            if (my_l > 0 && S->need_ratio[my_l]) u.w[tid] = mt::wigner_term(my_l, my_i, 0, my_b, my_s);
+        }
+        __syncthreads();
+        if (tid < 12) {  // one lane per ELEMENT: sum its terms in order, normalise (dmm's tail)
+            int l = 1, e = tid;
+            if (tid >= 3) { l = 2; e = tid - 3; }
+            if (tid >= 7) { l = 3; e = tid - 7; }
+            if (S->need_ratio[l]) {
+                int sl = 0;
+                for (int ll = 1; ll <= l; ll++)
+                    for (int ee = 0; ee <= ll + 1; ee++) {
+                        if (ll == l && ee == e) goto found;
+                        sl += ll - ((ee <= ll) ? ee : 0) + 1;
+                    }
+            found:
+                const int i = (e <= l) ? e : 0;
+                double sum = 0;
+                for (int s = 0; s <= l - i; s++) sum = sum + u.w[sl + s];
+                u.w[28 + tid] = mt::wigner_finish(l, i, 0, sum);
+            }
+        }
+        __syncthreads();
+        if (tid >= 1 && tid <= 3 && S->need_ratio[tid]) {  // mirror, centre overwrite, square (function_rot.cpp:25-41)
+            const int l = tid, base = 28 + (l == 1 ? 0 : (l == 2 ? 3 : 7));
+            double *V = S->ratios[l];
+            for (int i = 0; i <= l; i++) V[l + i] = u.w[base + i];
+            for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * mt::pow_m1(i);
+            V[l] = u.w[base + l + 1] * mt::pow_m1(0);
+            for (int i = 0; i <= 2 * l; i++) V[i] = V[i] * V[i];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < per; idx += nt) {  // rows go straight to the likelihood kernel's table
+            const int st = mt::build_multiplet(d.model_id, *u.poly, s_params, *S, idx, d.x_first, d.x_last, d.Nx, d.step,
+                                               &T.mults[(size_t)slot * per + idx]);
+            if (st) *u.status = st;
+        }
+        for (int i = tid; i < S->L.Nnoise; i += nt) T.noise[(size_t)slot * d.stride + i] = fabs(s_params[S->L.o_noise + i]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool ok = live && (*u.status == TAMCMC_OK);
+        T.pairs[2 * slot] = slot * per;
+        T.pairs[2 * slot + 1] = ok ? (slot + 1) * per : slot * per;
+        T.nh[slot] = ok ? S->nharvey : 0;
+        T.nn[slot] = ok ? S->L.Nnoise : 1;
+        if (!ok) T.noise[(size_t)slot * d.stride] = 1.0;  // placeholder row; the caller rejects / NaNs the evaluation
+    }
+}
+
+}  // namespace tamcmc

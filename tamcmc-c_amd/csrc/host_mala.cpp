@@ -259,28 +259,19 @@ int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const st
         std::memcpy(&P[c * (size_t)Np], model->params.row(live[c]), (size_t)Np * sizeof(double));
         T[c] = Tcoefs[(size_t)live[c]];
     }
-    int rc = tamcmc_hip_fd_gradient(model->get_ctx(), model->get_model_id(), (int)C, P.data(), Np, pl.data(), idx32.data(),
-                                    (int)Nvars, h.data(), T.data(), model->get_likelihood_params(), L0.data(), G.data());
+    // likelihood AND prior parts on the device: one workgroup per (chain, perturbed variable) builds its table and its prior
+    std::vector<int32_t> sw32(model->get_priors_switch().begin(), model->get_priors_switch().end());
+    std::vector<double> extra(model->get_extra_priors());
+    extra.resize(10, 0.0);
+    int rc = tamcmc_hip_fd_gradient_posterior(model->get_ctx(), model->get_model_id(), model->get_prior_class(), (int)C, P.data(), Np,
+                                              pl.data(), idx32.data(), (int)Nvars, h.data(), T.data(), model->get_likelihood_params(),
+                                              model->get_priors().a.data(), sw32.data(), extra.data(), L0.data(), nullptr, G.data());
     if (rc == TAMCMC_ERR_EMPTY_WINDOW || rc == TAMCMC_ERR_NAN_WINDOW) rc = TAMCMC_OK;
-    std::vector<double> p((size_t)Np);
     for (size_t c = 0; c < C; c++) {
         const int m = live[c];
-        const long double pr0 = model->call_prior_params(model->params.row(m));
         for (long k = 0; k < Nvars; k++) {
-            std::memcpy(p.data(), model->params.row(m), (size_t)Np * sizeof(double));
-            const double x0 = p[(size_t)idx[(size_t)k]];
-            p[(size_t)idx[(size_t)k]] = x0 + h[(size_t)k];
-            long double pr1 = model->call_prior_params(p.data());
-            double gp;
-            if (std::isfinite((double)pr1)) gp = (double)((pr1 - pr0) / h[(size_t)k]);
-            else {  // the forward point leaves the prior support: backward difference, else flat
-                p[(size_t)idx[(size_t)k]] = x0 - h[(size_t)k];
-                pr1 = model->call_prior_params(p.data());
-                gp = std::isfinite((double)pr1) ? (double)((pr0 - pr1) / h[(size_t)k]) : 0.0;
-            }
-            double gl = G[c * (size_t)Nvars + (size_t)k];
-            if (!std::isfinite(gl)) gl = 0.0;
-            grad_out(m, k) = gl + gp;
+            const double g = G[c * (size_t)Nvars + (size_t)k];
+            grad_out(m, k) = std::isfinite(g) ? g : 0.0;
         }
     }
     return rc;

@@ -116,6 +116,10 @@ class Model_def {  // model_def.h:27-85
     int get_model_id() const { return model_fct_name_switch; }
     double get_likelihood_params() const { return likelihood_params; }
     tamcmc_hip_ctx *get_ctx() const { return ctx; }
+    int get_prior_class() const { return prior_fct_name_switch; }
+    const Matrix &get_priors() const { return priors_params; }
+    const std::vector<int> &get_priors_switch() const { return priors_params_names_switch; }
+    const std::vector<double> &get_extra_priors() const { return extra_priors; }
 
     std::vector<double> call_model(Data *data_struc, int m);                        // model_def.cpp:220
     void update_params_with_vars(long m);                                            // model_def.cpp:484

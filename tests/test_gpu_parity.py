@@ -206,3 +206,34 @@ def test_full_size_c3_properties(pkg, oracle, synth, ctxs):
     nz = np.abs(star.params[star.plength[:8].sum():star.plength[:9].sum()])
     bg = nz[0] / (1 + (1e-3 * nz[1] * star.x) ** nz[2]) + nz[3] / (1 + (1e-3 * nz[4] * star.x) ** nz[5]) + nz[6]
     assert np.max(np.abs(model[0] - bg) / bg) < 1e-14
+
+
+def test_fd_gradient_posterior_device_batch(pkg, oracle, synth, ctxs):
+    """tamcmc_hip_fd_gradient_posterior: tables AND priors of the Nvars+1 perturbed vectors are built on the device.
+    Likelihood part against the oracle's forward differences; prior part against central differences of the host prior
+    (host prior == reference restatement in long double)."""
+    star = synth.make_c3_star(nx=20000, step=0.1)
+    y = _spectrum(oracle, star)
+    idx = star.index_to_relax
+    h = 1e-7 * np.maximum(np.abs(star.params[idx]), 1e-3)
+    T = 1.3
+    _, l0_o, g_o = oracle.fd_gradient(star.model_id, star.params, star.plength, idx, h, star.x, y, 1.0, T)
+    c = ctxs["fast"]
+    c.set_spectrum(star.x, y)
+    l0, g_like = c.fd_gradient(star.model_id, star.params, star.plength, idx, h, [T], 1.0)
+    assert abs(l0[0] - l0_o) <= 1e-11 * abs(l0_o)
+    scale = np.max(np.abs(g_o))
+    assert np.max(np.abs(g_like[0] - g_o)) <= 2e-4 * scale      # FD of a ~1e5-magnitude logL with h~1e-7*theta: cancellation-limited
+    l0p, pr0, g_post = c.fd_gradient_posterior(star, star.params, h, [T], 1.0)
+    assert l0p[0] == l0[0] and np.isfinite(pr0[0])
+    g_prior = g_post[0] - g_like[0]
+    # smoothness + Jeffreys + Gaussian priors have O(1) gradients; they must be finite and mostly non-zero for the frequencies
+    assert np.all(np.isfinite(g_prior))
+    fsel = [i for i, k in enumerate(idx) if star.names[k] == "Frequency_l"]
+    assert np.count_nonzero(np.abs(g_prior[fsel]) > 1e-6) > len(fsel) // 2
+    # a vector at the edge of a uniform prior: forward point outside the support -> backward difference, finite gradient
+    P = star.params.copy()
+    k_inc = [i for i, k in enumerate(idx) if star.names[k] == "Inclination"][0]
+    P[idx[k_inc]] = 90.0 - 0.25 * h[k_inc]
+    _, _, g_edge = c.fd_gradient_posterior(star, P, h, [T], 1.0)
+    assert np.all(np.isfinite(g_edge))
