@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
 
     const int m = blockIdx.x, tid = threadIdx.x;
     const int Q = P ^ 1;
-#define STAMP(k) do { if (a.dbg && m == 0 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
+#define STAMP(k) do { if (PROPOSE && a.dbg && m == 0 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
     STAMP(0);
     const double *curv = a.vars_cur + (size_t)P * C * Nv, *curp = a.params_cur + (size_t)P * C * Np;
     const double *prpv = a.vars_prop + (size_t)P * C * Nv, *prpp = a.params_prop + (size_t)P * C * Np;
@@ -554,8 +554,8 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         long h[8];
         DCHK(hipMemcpyAsync(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost, st));
         DCHK(hipStreamSynchronize(st));
-        fprintf(stderr, "[k_iterate stamps us] rng+matvec %.2f | scatter+prior %.2f | unpack %.2f (settle is timed by k_iterate<false>)\n",
-                (h[2] - h[1]) * 0.01, (h[4] - h[2]) * 0.01, (h[6] - h[4]) * 0.01);
+        fprintf(stderr, "[k_iterate stamps us] settle %.2f | rng+matvec %.2f | scatter+prior %.2f | unpack %.2f\n",
+                (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[4] - h[2]) * 0.01, (h[6] - h[4]) * 0.01);
     }
     DCHK(hipGetLastError());
     if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));

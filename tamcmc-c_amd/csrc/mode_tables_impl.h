@@ -98,7 +98,16 @@ TM_HD void fill_poly(PolyTab &t) {
 }
 
 // ---------- m-visibilities: function_rot.cpp:15-101 ----------
-TM_HD int ifact(int n) {
+TM_HD int ifact(int n) {  // function_rot.cpp:94-101 (n <= 6 on this path: table; same values as the loop)
+    if (n <= 1) return 1;
+    switch (n) {
+    case 2: return 2;
+    case 3: return 6;
+    case 4: return 24;
+    case 5: return 120;
+    case 6: return 720;
+    default: break;
+    }
     long f = 1;
     for (long i = 1; i <= n; i++) f *= i;
     return (int)f;
@@ -151,23 +160,28 @@ TM_HD void amplitude_ratio(int l, double beta_deg, double *V) {
 }
 
 // ---------- interpol.cpp:13-43, linfit.cpp:17-35, models.cpp:6065-6084 ----------
-TM_HD double lin_interpol(const double *x, const double *y, long n, double xi) {
-    double a = 0, b = 0;
+// segment of the abscissa grid used by lin_interpol for xi: -1 none (NaN), else the left index of the segment
+TM_HD long lin_segment(const double *x, long n, double xi) {
+    long seg = -1;
     if (xi >= x[0] && xi <= x[n - 1]) {
         long i = 0;
         while (i < n - 2 && (xi < x[i] || xi > x[i + 1])) ++i;
-        a = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
-        b = y[i] - a * x[i];
+        seg = i;
     }
-    if (xi < x[0]) {
-        a = (y[1] - y[0]) / (x[1] - x[0]);
-        b = y[0] - a * x[0];
-    }
-    if (xi > x[n - 1]) {
-        a = (y[n - 1] - y[n - 2]) / (x[n - 1] - x[n - 2]);
-        b = y[n - 2] - a * x[n - 2];
+    if (xi < x[0]) seg = 0;
+    if (xi > x[n - 1]) seg = n - 2;
+    return seg;
+}
+TM_HD double lin_interpol_seg(const double *x, const double *y, long seg, double xi) {
+    double a = 0, b = 0;
+    if (seg >= 0) {
+        a = (y[seg + 1] - y[seg]) / (x[seg + 1] - x[seg]);  // slope
+        b = y[seg] - a * x[seg];                            // ordinate at origin
     }
     return a * xi + b;
+}
+TM_HD double lin_interpol(const double *x, const double *y, long n, double xi) {
+    return lin_interpol_seg(x, y, lin_segment(x, n, xi), xi);
 }
 // slope/intercept of y against the index 0..n-1 (linfit with x = LinSpaced(n, 0, n-1))
 TM_HD void linfit_index(const double *y, long n, double out[2]) {
@@ -368,10 +382,12 @@ TM_HD int build_multiplet(int model_id, const PolyTab &T, const double *p, const
             eta0 = 0.0;  // the l=0 call passes eta0 = 0 (models.cpp:1296)
         } else {
             const double *sp = p + L.o_split;
-            W = fabs(lin_interpol(fl0, Wl0, L.Nfl[0], f));
-            if (S.do_amp) H = (double)xabs(lin_interpol(fl0, Hl0, L.Nfl[0], f) / (pi * W) * S.Vl[l]);
-            else H = fabs(lin_interpol(fl0, Hl0, L.Nfl[0], f) * S.Vl[l]);
-            for (int j = 1; j <= 2 * l; j++) a[j] = sp[2 * (j - 1)] + sp[2 * (j - 1) + 1] * (f * 1e-3);
+            const long seg = lin_segment(fl0, L.Nfl[0], f);  // widths and heights share the abscissa search
+            W = fabs(lin_interpol_seg(fl0, Wl0, seg, f));
+            if (S.do_amp) H = (double)xabs(lin_interpol_seg(fl0, Hl0, seg, f) / (pi * W) * S.Vl[l]);
+            else H = fabs(lin_interpol_seg(fl0, Hl0, seg, f) * S.Vl[l]);
+            // a_j(nu) = aj0 + aj1 nu[mHz] for j <= 2l (models.cpp:1314-1367); constant trip count keeps a[] in registers
+            for (int j = 1; j <= 6; j++) a[j] = (j <= 2 * l) ? sp[2 * (j - 1)] + sp[2 * (j - 1) + 1] * (f * 1e-3) : 0.0;
         }
         f_s = a[1];
     } else if (model_id == TAMCMC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC) {
