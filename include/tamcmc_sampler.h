@@ -71,6 +71,12 @@ int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL
 int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, double *covarmat);
 int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, const double *covarmat, double sigma);
 
+/* Host log-prior of one parameter vector = Model_def::call_prior (model_def.cpp:421-464) for the model classes
+ * io_MS_Global (2) and io_local (3): long double arithmetic, the reference's term order.  *status (may be NULL) receives
+ * TAMCMC_ERR_BAD_MODEL for prior ids / model families this build does not carry. */
+double tamcmc_log_prior(int prior_class, const double *params, int64_t Nparams, const int32_t *plength, const double *priors,
+                        const int32_t *priors_switch, const double *extra_priors, int32_t n_extra, int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

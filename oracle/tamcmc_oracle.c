@@ -718,3 +718,106 @@ long double orc_apply_generic_priors(const double *params, long i0, long n, cons
     }
     return pena;
 }
+
+/* second differences with replicated edges: Scndder_adaptive_reggrid(y) (derivatives_handler.cpp:400-426,
+ * forward :248-268 at the first point, backward at the last, centred :294-314 in between; unit spacing) */
+static double orc_second_difference(const double *y, long n, long i) {
+    if (n < 3) return 0.0;
+    if (i == 0) return y[2] - 2. * y[1] + y[0];
+    if (i == n - 1) return y[n - 1] - 2. * y[n - 2] + y[n - 3];
+    return y[i + 1] - 2. * y[i] + y[i - 1];
+}
+
+/* priors_calc.cpp:27-317 -- model class io_MS_Global.  Restated for the model families this build ships:
+ * model_index 9 (aj family, :206-228) and the default branch (Classic, :230-262 with impose_normHnlm = 0).
+ * Other families return NaN (the reference exits with "needs checks" for most of them). */
+long double orc_priors_MS_Global(const double *params, const int *pl, const double *pr, const int *sw, const double *extra) {
+    long double f = 0;
+    const int smooth_switch = (int)extra[0];
+    const double scoef = extra[1];
+    const double *ajova1_limit = &extra[2];
+    const int impose_normHnlm = (int)extra[8];
+    const int model_index = (int)extra[9];
+    const int Nmax = pl[0], lmax = pl[1];
+    const int Nfl[4] = {pl[2], pl[3], pl[4], pl[5]};
+    const int Nsplit = pl[6], Nwidth = pl[7];
+    const int Nf = Nfl[0] + Nfl[1] + Nfl[2] + Nfl[3];
+    long Np = 0;
+    for (int i = 0; i < 11; i++) Np += pl[i];
+    for (int i = Nmax; i <= Nmax + lmax; i++)
+        if (params[i] < 0) return -INFINITY;
+    if (model_index == 9) {
+        int i0 = Nfl[0];
+        for (int el = 1; el < lmax + 1; el++) {
+            for (int j = 1; j < 6; j++)
+                for (int n = 0; n < Nfl[el]; n++) {
+                    double fl = params[Nmax + lmax + i0 + n];
+                    double a1 = params[Nmax + lmax + Nf] + params[Nmax + lmax + Nf + 1] * (fl * 1e-3);
+                    double aj = params[Nmax + lmax + Nf + 2 * j] + params[Nmax + lmax + Nf + 2 * j + 1] * (fl * 1e-3);
+                    if (fabs(aj / a1) >= ajova1_limit[j]) return -INFINITY;
+                    if (a1 < 0) return -INFINITY;
+                }
+            i0 = i0 + Nfl[el];
+        }
+    } else if (model_index >= 0 && model_index <= 8) {
+        return NAN;
+    } else if (impose_normHnlm != 0) {
+        return NAN;
+    }
+    const int on = Nmax + lmax + Nf + Nsplit + Nwidth;
+    if (sw[on + 3] != 0)
+        if ((params[on + 3] < 0) || (params[on + 4] < 0) || (params[on + 5] < 0)) return -INFINITY;
+    if (sw[on + 6] != 0)
+        if ((params[on + 6] < 0) || (params[on + 7] < 0) || (params[on + 8] < 0)) return -INFINITY;
+    if ((sw[Nmax + lmax + Nf + 9] != 0) && (params[on + 9] < 0)) return -INFINITY; /* index quirk of :272 kept */
+    f = f + orc_apply_generic_priors(params, 0, Np, pr, Np, sw);
+    double *idx = (double *)malloc(sizeof(double) * (size_t)(Nfl[0] > 0 ? Nfl[0] : 1));
+    double fit[2];
+    for (int i = 0; i < Nfl[0]; i++) idx[i] = (double)i;
+    orc_linfit(idx, params + Nmax + lmax, Nfl[0], fit);
+    free(idx);
+    const double Dnu = fit[0];
+    if (Nfl[0] == Nfl[2])
+        for (int i = 0; i < Nfl[0]; i++) {
+            double d02 = params[Nmax + lmax + i] - params[Nmax + lmax + Nfl[0] + Nfl[1] + i];
+            f = f + orc_logP_gaussian_uniform(0, Dnu / 3., 0.015 * Dnu, d02);
+        }
+    if (smooth_switch == 1) {
+        int i0 = 0;
+        for (int el = 0; el < lmax + 1; el++) {
+            if (Nfl[el] != 0)
+                for (int i = 0; i < Nfl[el]; i++)
+                    f = f + orc_logP_gaussian(0, scoef, orc_second_difference(params + Nmax + lmax + i0, Nfl[el], i));
+            i0 = i0 + Nfl[el];
+        }
+    }
+    return f;
+}
+
+/* priors_calc.cpp:514-629 -- model class io_local */
+long double orc_priors_local(const double *params, const int *pl, const double *pr, const int *sw, const double *extra) {
+    long double f = 0;
+    const double a3ova1_limit = extra[2];
+    const int Nmax = pl[0], Nvis = pl[1];
+    const int Nf = pl[2] + pl[3] + pl[4] + pl[5];
+    const int Nsplit = pl[6], Nwidth = pl[7], Nnoise = pl[8];
+    long Np = 0;
+    for (int i = 0; i < 11; i++) Np += pl[i];
+    const int o = Nmax + Nvis + Nf;
+    if (params[o] != 0) {
+        if (fabs(params[o + 2] / params[o]) >= a3ova1_limit) return -INFINITY;
+    } else if ((params[o + 3] != 0) && (params[o + 4] != 0)) {
+        if (fabs(params[o + 2] / (pow(params[o + 3], 2) + pow(params[o + 4], 2))) >= a3ova1_limit) return -INFINITY;
+    }
+    const int oi = o + Nsplit + Nwidth + Nnoise;
+    if ((sw[oi] != 0) && (params[oi] < 0)) return -INFINITY;
+    f = f + orc_apply_generic_priors(params, 0, Np, pr, Np, sw);
+    return f;
+}
+
+/* call_prior (model_def.cpp:421-464): class 2 = io_MS_Global, 3 = io_local */
+double orc_call_prior(int prior_class, const double *params, const int *pl, const double *pr, const int *sw, const double *extra) {
+    if (prior_class == 2) return (double)orc_priors_MS_Global(params, pl, pr, sw, extra);
+    if (prior_class == 3) return (double)orc_priors_local(params, pl, pr, sw, extra);
+    return NAN;
+}

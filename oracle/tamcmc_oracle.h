@@ -122,6 +122,14 @@ long double orc_logP_gug(double b_min, double b_max, double sigma1, double sigma
 long double orc_apply_generic_priors(const double *params, long i0, long n, const double *priors, long Nparams,
                                      const int *priors_names_switch);
 
+/* model-class priors (priors_calc.cpp:27-317, :514-629) and call_prior (model_def.cpp:421-464) */
+long double orc_priors_MS_Global(const double *params, const int *plength, const double *priors, const int *priors_names_switch,
+                                 const double *extra_priors);
+long double orc_priors_local(const double *params, const int *plength, const double *priors, const int *priors_names_switch,
+                             const double *extra_priors);
+double orc_call_prior(int prior_class, const double *params, const int *plength, const double *priors,
+                      const int *priors_names_switch, const double *extra_priors);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,8 @@
 // host_capi.cpp -- C ABI of include/tamcmc_sampler.h over the host-side Model_def / MALA mirrors.
+#include <cmath>
 #include <cstring>
 #include <memory>
+#include <vector>
 #include <string>
 
 #include "../../include/tamcmc_sampler.h"
@@ -191,6 +193,27 @@ int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, 
         return s->dev->upload_proposal(m, s->mala->factor(m).a.data(), s->mala->covarmat[(size_t)m].a.data(), s->mala->mu.row(m),
                                        s->mala->sigma[(size_t)m]);
     return TAMCMC_OK;
+}
+
+double tamcmc_log_prior(int prior_class, const double *params, int64_t Nparams, const int32_t *plength, const double *priors,
+                        const int32_t *priors_switch, const double *extra_priors, int32_t n_extra, int32_t *status) {
+    if (status) *status = TAMCMC_OK;
+    if (!params || !plength || !priors || !priors_switch || !extra_priors || Nparams < 1) {
+        if (status) *status = TAMCMC_ERR_BAD_ARG;
+        return NAN;
+    }
+    std::vector<int> pl(plength, plength + 11), sw(priors_switch, priors_switch + Nparams);
+    std::vector<double> extra(10, 0.0);
+    for (int i = 0; i < n_extra && i < 10; i++) extra[(size_t)i] = extra_priors[i];
+    Matrix pp(4, Nparams);
+    std::memcpy(pp.a.data(), priors, 4 * (size_t)Nparams * sizeof(double));
+    int st = TAMCMC_OK;
+    long double r;
+    if (prior_class == 2) r = priors_MS_Global(params, pl, pp, sw, extra, &st);
+    else if (prior_class == 3) r = priors_local(params, pl, pp, sw, extra, &st);
+    else { st = TAMCMC_ERR_BAD_MODEL; r = NAN; }
+    if (status) *status = st;
+    return (double)r;
 }
 
 }  // extern "C"

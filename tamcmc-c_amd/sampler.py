@@ -28,6 +28,7 @@ EXTRA_ABI += [
     ("tamcmc_sampler_get_state", C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _i64p]),
     ("tamcmc_sampler_get_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp]),
     ("tamcmc_sampler_set_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_double]),
+    ("tamcmc_log_prior", C.c_double, [C.c_int, _dp, C.c_int64, _ip, _dp, _ip, _dp, C.c_int32, _ip]),
 ]
 
 
@@ -140,3 +141,13 @@ def default_errors(star):
                 frac, off = f, o
         err.append(abs(star.params[i]) * frac + off)
     return np.array(err)
+
+
+def log_prior(star, params=None):
+    """Host log-prior (Model_def::call_prior) of `star`'s model class at `params` (default: the star's own vector)."""
+    L = _rebind()
+    p = _f64(star.params if params is None else params)
+    pl, pr, sw, ex = _i32(star.plength), _f64(star.priors), _i32(star.priors_switch), _f64(star.extra_priors)
+    st = C.c_int32(0)
+    v = L.tamcmc_log_prior(int(star.prior_class), _p(p), p.size, _p(pl, _ip), _p(pr), _p(sw, _ip), _p(ex), ex.size, C.byref(st))
+    return float(v), int(st.value)

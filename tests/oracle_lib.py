@@ -83,6 +83,8 @@ def load(fast=False):
         f.argtypes = [C.c_double] * n
     lib.orc_apply_generic_priors.restype = ld
     lib.orc_apply_generic_priors.argtypes = [c_dp, C.c_long, C.c_long, c_dp, C.c_long, c_ip]
+    lib.orc_call_prior.restype = C.c_double
+    lib.orc_call_prior.argtypes = [C.c_int, c_dp, c_ip, c_dp, c_ip, c_dp]
     return lib
 
 
@@ -149,3 +151,11 @@ class Oracle:
         st = self.lib.orc_fd_gradient(model_id, _dp(params), params.size, _ip(plength), _ip(idx), idx.size, _dp(h),
                                       _dp(x), _dp(y), x.size, float(p), float(Tcoef), C.byref(l0), _dp(g))
         return st, l0.value, g
+
+    def call_prior(self, star, params=None):
+        p = np.ascontiguousarray(star.params if params is None else params, dtype=np.float64)
+        pl = np.ascontiguousarray(star.plength, dtype=np.int32)
+        pr = np.ascontiguousarray(star.priors, dtype=np.float64)
+        sw = np.ascontiguousarray(star.priors_switch, dtype=np.int32)
+        ex = np.ascontiguousarray(star.extra_priors, dtype=np.float64)
+        return float(self.lib.orc_call_prior(int(star.prior_class), _dp(p), _ip(pl), _dp(pr), _ip(sw), _dp(ex)))
