@@ -71,6 +71,23 @@ int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL
 int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, double *covarmat);
 int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, const double *covarmat, double sigma);
 
+/* ---- the reference's on-disk sample formats (outputs.cpp:1231-1333, :1472-1550) and summary statistics ---- */
+/* <root>params.hdr + <root>params_chain-<m>.bin: raw little-endian doubles [sample][var]; samples = [n x Nchains x Nvars]
+ * exactly as tamcmc_sampler_run returns them.  names (may be NULL) = Nparams parameter names for the header. */
+int tamcmc_outputs_write_params(const char *root, const double *samples, int64_t n, int32_t Nchains, int32_t Nvars,
+                                int64_t Nsamples_total, const int32_t *relax, const int32_t *plength, int64_t Nparams,
+                                const double *inputs, const char *const *names, int32_t append);
+/* <root>stat_criteria.hdr/.bin: per sample logLikelihood[0:Nchains], logPrior[0:Nchains], logPosterior[0:Nchains];
+ * stats = [n x Nchains x 3] as tamcmc_sampler_run returns them. */
+int tamcmc_outputs_write_stat_criteria(const char *root, const double *stats, int64_t n, int32_t Nchains, int32_t append);
+/* reads back one chain (what tools/bin2txt_params.cpp does); samples may be NULL to query the count */
+int tamcmc_outputs_read_params(const char *root, int32_t chain, double *samples, int64_t max_samples, int64_t *n_read,
+                               int32_t *Nchains, int32_t *Nvars);
+/* mean, median, population standard deviation per variable (tools/quick_samples_stats.cpp:4-35 via bin2txt_params.cpp:165-168);
+ * samples rows are row_stride doubles apart */
+int tamcmc_params_summary(const double *samples, int64_t n, int32_t Nvars, int64_t row_stride, double *mean, double *median,
+                          double *stddev);
+
 /* Host log-prior of one parameter vector = Model_def::call_prior (model_def.cpp:421-464) for the model classes
  * io_MS_Global (2) and io_local (3): long double arithmetic, the reference's term order.  *status (may be NULL) receives
  * TAMCMC_ERR_BAD_MODEL for prior ids / model families this build does not carry. */

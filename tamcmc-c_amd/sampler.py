@@ -28,6 +28,11 @@ EXTRA_ABI += [
     ("tamcmc_sampler_get_state", C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _i64p]),
     ("tamcmc_sampler_get_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp]),
     ("tamcmc_sampler_set_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_double]),
+    ("tamcmc_outputs_write_params", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, C.c_int64, _dp,
+                                             C.POINTER(C.c_char_p), C.c_int32]),
+    ("tamcmc_outputs_write_stat_criteria", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32]),
+    ("tamcmc_outputs_read_params", C.c_int, [C.c_char_p, C.c_int32, _dp, C.c_int64, _i64p, _ip, _ip]),
+    ("tamcmc_params_summary", C.c_int, [_dp, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, _dp]),
     ("tamcmc_log_prior", C.c_double, [C.c_int, _dp, C.c_int64, _ip, _dp, _ip, _dp, C.c_int32, _ip]),
 ]
 
@@ -151,3 +156,43 @@ def log_prior(star, params=None):
     st = C.c_int32(0)
     v = L.tamcmc_log_prior(int(star.prior_class), _p(p), p.size, _p(pl, _ip), _p(pr), _p(sw, _ip), _p(ex), ex.size, C.byref(st))
     return float(v), int(st.value)
+
+
+def write_outputs(root, star, samples, stats=None, nsamples_total=None, append=False):
+    """Writes the reference's params.hdr / params_chain-<m>.bin (+ stat_criteria) files for samples [n x Nchains x Nvars]."""
+    L = _rebind()
+    smp = _f64(samples)
+    n, nc, nv = smp.shape
+    names = (C.c_char_p * len(star.names))(*[s.encode() for s in star.names])
+    st = L.tamcmc_outputs_write_params(str(root).encode(), _p(smp), n, nc, nv, int(nsamples_total or n), _p(_i32(star.relax), _ip),
+                                       _p(_i32(star.plength), _ip), star.params.size, _p(_f64(star.params)), names, int(append))
+    if st != OK:
+        raise TamcmcError(st, "tamcmc_outputs_write_params")
+    if stats is not None:
+        stt = _f64(stats)
+        st = L.tamcmc_outputs_write_stat_criteria(str(root).encode(), _p(stt), stt.shape[0], nc, int(append))
+        if st != OK:
+            raise TamcmcError(st, "tamcmc_outputs_write_stat_criteria")
+
+
+def read_params(root, chain):
+    L = _rebind()
+    n, nc, nv = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    st = L.tamcmc_outputs_read_params(str(root).encode(), int(chain), None, 0, C.byref(n), C.byref(nc), C.byref(nv))
+    if st != OK:
+        raise TamcmcError(st, "tamcmc_outputs_read_params")
+    out = np.zeros((n.value, nv.value))
+    L.tamcmc_outputs_read_params(str(root).encode(), int(chain), _p(out), n.value, C.byref(n), C.byref(nc), C.byref(nv))
+    return out
+
+
+def params_summary(samples2d):
+    """mean / median / stddev per variable of [n x Nvars] samples (bin2txt's summary)."""
+    L = _rebind()
+    a = _f64(samples2d)
+    n, nv = a.shape
+    mean, med, sd = np.zeros(nv), np.zeros(nv), np.zeros(nv)
+    st = L.tamcmc_params_summary(_p(a), n, nv, nv, _p(mean), _p(med), _p(sd))
+    if st != OK:
+        raise TamcmcError(st, "tamcmc_params_summary")
+    return mean, med, sd
