@@ -36,6 +36,7 @@ constexpr int CHUNK = 64;  // multiplets staged per pass: one wave compacts one 
 constexpr int F_FULL = 1;  // window covers every bin of the tile
 constexpr int F_SAFE = 2;  // FAST: product of the 2l+1 denominators stays far below DBL_MAX on this tile
 constexpr int F_ASYM = 4;  // asymmetry coefficient != 0
+constexpr int F_FAR = 8;   // FAST far field: the multiplet joins the tile polynomial instead of the per-bin loop
 
 // arithmetic modes of k_loglike (see include/tamcmc_hip.h)
 constexpr int M_STRICT = 0, M_FAST_DIRECT = 2, M_FAST = 1;
@@ -223,14 +224,14 @@ template <int MODE, int K, bool WRITE_MODEL>
 __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     constexpr bool FAST = (MODE != M_STRICT);
     constexpr bool FARFIELD = (MODE == M_FAST);
-    // near list and (after the multiplet loop) the coefficient-reduction rows share one LDS region
+    // multiplet list and (after the multiplet loop) the coefficient-reduction rows share one LDS region
     constexpr int LDS_BYTES = FARFIELD ? (WG * ROW * 8 > CHUNK * (int)sizeof(LdsMult) ? WG * ROW * 8 : CHUNK * (int)sizeof(LdsMult))
                                        : CHUNK * (int)sizeof(LdsMult);
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[LDS_BYTES];
     LdsMult *s_m = (LdsMult *)s_buf;
     double *s_rows = (double *)s_buf;
     __shared__ int s_n, s_nfar, s_anyfar;
-    __shared__ int s_far[CHUNK];          // FARFIELD: global indices of this chunk's far multiplets
+    __shared__ int s_far[CHUNK];          // FARFIELD: positions (in s_m) of this chunk's far multiplets
     __shared__ double s_coef[NC];         // FARFIELD: the tile's far-field polynomial
     __shared__ double s_part[16][NC];
     __shared__ double s_red[2 * (WG / 64)];
@@ -262,23 +263,25 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     const double *nz = a.noise + (size_t)b * a.noise_stride;
     const int nh = a.nharvey[b];
     const int nn = a.nnoise[b];
-    if (FAST) {
-        if (tid < nh) s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
-    }
     // tile geometry for the far field: centre and half-width of the nominal tile on the regular grid
     const double h = 0.5 * (double)TILE * a.step;
     const double xc = a.x0 + ((double)t0 + 0.5 * (double)TILE - 0.5) * a.step;
-    double fcoef[NC];
     // FARFIELD: the background H/(1+(a x)^p) + N0 is analytic on the tile with its singularities ~x_c away, so it joins the
     // tile polynomial: u(s) = (a x_c)^p (1+eps s)^p (binomial series), then the reciprocal series of 1+u.
     const bool harvey_poly = FARFIELD && (fabs(h) <= EPS_MAX * fabs(xc)) && (xc > 0.0);
+    if (FAST && !harvey_poly) {
+        if (tid < nh) s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
+    }
+    double fcoef[NC];
     if (FARFIELD) {
 #pragma unroll
         for (int k = 0; k < NC; k++) fcoef[k] = 0.0;
         if (tid == 0) s_anyfar = harvey_poly ? 1 : 0;
         if (harvey_poly) {
-            if (tid < nh) {  // lane = Harvey term; its NH coefficients go to fcoef[0..NH) of that lane
-                const double Hh = nz[3 * tid], tau = nz[3 * tid + 1], pw = nz[3 * tid + 2];
+            // wave 1 (wave 0 is busy compacting the first chunk): lane = Harvey term, its NH coefficients go to that lane's fcoef
+            const int hl = tid - 64;
+            if (hl >= 0 && hl < nh) {
+                const double Hh = nz[3 * hl], tau = nz[3 * hl + 1], pw = nz[3 * hl + 2];
                 if (tau != 0.0) {
                     const double eps = h / xc;
                     double u[NH], f[NH];
@@ -298,7 +301,7 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                     for (int k = 0; k < NH; k++) fcoef[k] = f[k];
                 }
             }
-            if (tid == TAMCMC_MAX_HARVEY) fcoef[0] = nz[nn - 1];  // white noise joins the constant term
+            if (tid == 64 + TAMCMC_MAX_HARVEY) fcoef[0] = nz[nn - 1];  // white noise joins the constant term
         }
     }
 
@@ -314,27 +317,17 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                 i1 = a.mults[idx].i1;
                 ov = (i0 < t1) && (i1 > t0);
             }
+            const unsigned long long mask = __ballot(ov);
             bool far = false;
-            if (FARFIELD && ov && i0 <= t0 && i1 >= t1) {
-                const tamcmc_multiplet &g = a.mults[idx];
-                const double ig = 2.0 * rcp_nr2(g.gamma), beta2 = (ig * h) * (ig * h);
-                const double r2 = (g.asym != 0.0) ? RHO_MAX2_ASYM : RHO_MAX2;
-                far = true;
-                for (int m = 0; m < 2 * g.l + 1; m++) {
-                    const double A = ig * (g.nu[m] - xc);
-                    if (!(beta2 <= r2 * fma(A, A, 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
-                }
-            }
-            const unsigned long long fmask = __ballot(far);
-            const unsigned long long mask = __ballot(ov && !far);
-            if (far) s_far[__popcll(fmask & ((1ull << tid) - 1ull))] = idx;
-            if (ov && !far) {
+            if (ov) {
+                // every overlapping multiplet is staged (in order) with its per-multiplet scalars hoisted; far ones are flagged
                 const int pos = __popcll(mask & ((1ull << tid) - 1ull));
                 const tamcmc_multiplet &g = a.mults[idx];
                 LdsMult &d = s_m[pos];
                 const int l = g.l;
                 int flags = 0;
-                if (i0 <= t0 && i1 >= t1) flags |= F_FULL;
+                const bool full = (i0 <= t0 && i1 >= t1);
+                if (full) flags |= F_FULL;
                 if (g.asym != 0.0) flags |= F_ASYM;
                 const double c2 = 0.5 * g.gamma * g.asym / g.fc;
                 d.c2sq = c2 * c2;
@@ -343,14 +336,26 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                     const double ig = 2.0 * rcp_nr2(g.gamma);
                     d.g = ig;
                     d.fcx = g.asym / g.fc;
-                    // prod_m (1 + ((x-nu_m) ig)^2) < (1e38)^7 = 1e266 on the whole tile?
-                    const double xlo = a.x[t0], xhi = a.x[t1 - 1];
-                    bool safe = true;
-                    for (int m = 0; m < 2 * l + 1; m++) {
-                        const double dm = fmax(fabs(xlo - g.nu[m]), fabs(xhi - g.nu[m])) * ig;
-                        if (!(fma(dm, dm, 1.0) < 1e38)) safe = false;  // also false for NaN/inf inputs
+                    if (FARFIELD && full) {
+                        const double beta2 = (ig * h) * (ig * h);
+                        const double r2 = (g.asym != 0.0) ? RHO_MAX2_ASYM : RHO_MAX2;
+                        far = true;
+                        for (int m = 0; m < 2 * l + 1; m++) {
+                            const double A = ig * (g.nu[m] - xc);
+                            if (!(beta2 <= r2 * fma(A, A, 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
+                        }
                     }
-                    if (safe) flags |= F_SAFE;
+                    if (far) flags |= F_FAR;
+                    else {
+                        // prod_m (1 + ((x-nu_m) ig)^2) < (1e38)^7 = 1e266 on the whole tile?
+                        const double xlo = a.x[t0], xhi = a.x[t1 - 1];
+                        bool safe = true;
+                        for (int m = 0; m < 2 * l + 1; m++) {
+                            const double dm = fmax(fabs(xlo - g.nu[m]), fabs(xhi - g.nu[m])) * ig;
+                            if (!(fma(dm, dm, 1.0) < 1e38)) safe = false;  // also false for NaN/inf inputs
+                        }
+                        if (safe) flags |= F_SAFE;
+                    }
                 } else {
                     d.g = g.gamma * g.gamma;
                     d.fcx = g.fc;
@@ -359,47 +364,63 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 7; m++) d.nh[m] = make_double2(g.nu[m], g.hv[m]);
             }
-            if (tid == 0) {
-                s_nfar = __popcll(fmask);
-                if (fmask) s_anyfar = 1;
+            if (FARFIELD) {
+                const unsigned long long fmask = __ballot(far);
+                if (far) s_far[__popcll(fmask & ((1ull << tid) - 1ull))] = __popcll(mask & ((1ull << tid) - 1ull));
+                if (tid == 0) {
+                    s_nfar = __popcll(fmask);
+                    if (fmask) s_anyfar = 1;
+                }
             }
             if (tid == 0) s_n = __popcll(mask);
         }
         __syncthreads();
         const int n = s_n;
         if (FARFIELD) {
-            // one lane per (far multiplet, m) slot: its NC Taylor coefficients, accumulated in registers
+            // one lane per (far multiplet, m) slot: its NC Taylor coefficients, added to the lane's running vector
             const int nslots = s_nfar * 7;
             for (int slot = tid; slot < nslots; slot += WG) {
                 const int jf = slot / 7, mm = slot - jf * 7;
-                const tamcmc_multiplet &g = a.mults[s_far[jf]];
-                if (mm < 2 * g.l + 1) {
-                    const double ig = 2.0 * rcp_nr2(g.gamma), beta = ig * h;
-                    const double A = ig * (g.nu[mm] - xc);
+                const LdsMult &M = s_m[s_far[jf]];
+                if (mm < 2 * M.l + 1) {
+                    const double2 nhm = M.nh[mm];
+                    const double beta = M.g * h;
+                    const double A = M.g * (nhm.x - xc);
                     const double inv = rcp_nr2(fma(A, A, 1.0));
                     const double two_req = 2.0 * beta * A * inv, q2 = beta * beta * inv;
-                    double c[NC];
-                    c[0] = g.hv[mm] * inv;
-                    c[1] = c[0] * two_req;
+                    double cm = nhm.y * inv;      // c_0
+                    double cc = cm * two_req;     // c_1
+                    if (!(M.flags & F_ASYM)) {
+                        fcoef[0] = fcoef[0] + cm;
+                        fcoef[1] = fcoef[1] + cc;
 #pragma unroll
-                    for (int k = 1; k < NC - 1; k++) c[k + 1] = fma(two_req, c[k], -q2 * c[k - 1]);
-                    if (g.asym != 0.0) {
-                        // times the asymmetry factor (1+asym(x/nu_c-1))^2 + c2^2 = A0 + A1 s + A2 s^2
-                        const double p0 = fma(g.asym, xc / g.fc - 1.0, 1.0), p1 = g.asym * h / g.fc;
-                        const double c2 = 0.5 * g.gamma * g.asym / g.fc;
-                        const double A0 = fma(p0, p0, c2 * c2), A1 = 2.0 * p0 * p1, A2 = p1 * p1;
+                        for (int k = 2; k < NC; k++) {
+                            const double cn = fma(two_req, cc, -q2 * cm);
+                            fcoef[k] = fcoef[k] + cn;
+                            cm = cc;
+                            cc = cn;
+                        }
+                    } else {
+                        // times the asymmetry factor (1+asym(x/nu_c-1))^2 + c2^2 = A0 + A1 s + A2 s^2 (M.fcx = asym/nu_c)
+                        const double p0 = fma(M.fcx, xc, 1.0 - M.asym), p1 = M.fcx * h;
+                        const double A0 = fma(p0, p0, M.c2sq), A1 = 2.0 * p0 * p1, A2 = p1 * p1;
+                        double c2 = 0.0, c1 = 0.0, c0k = cm;  // c_{k-2}, c_{k-1}, c_k
+                        double nxt = cc;
 #pragma unroll
-                        for (int k = NC - 1; k >= 2; k--) c[k] = fma(A0, c[k], fma(A1, c[k - 1], A2 * c[k - 2]));
-                        c[1] = fma(A0, c[1], A1 * c[0]);
-                        c[0] = A0 * c[0];
+                        for (int k = 0; k < NC; k++) {
+                            fcoef[k] = fcoef[k] + fma(A0, c0k, fma(A1, c1, A2 * c2));
+                            const double cn = (k == 0) ? nxt : fma(two_req, c0k, -q2 * c1);
+                            c2 = c1;
+                            c1 = c0k;
+                            c0k = cn;
+                        }
                     }
-#pragma unroll
-                    for (int k = 0; k < NC; k++) fcoef[k] = fcoef[k] + c[k];
                 }
             }
         }
         for (int q = 0; q < n; q++) {
             const LdsMult &M = s_m[q];
+            if (FARFIELD && (M.flags & F_FAR)) continue;  // wave-uniform
             switch (M.l) {  // wave-uniform
             case 0: mult_dispatch<FAST, 1, K>(M, xv, bin, acc); break;
             case 1: mult_dispatch<FAST, 3, K>(M, xv, bin, acc); break;
@@ -408,10 +429,10 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
             }
         }
     }
-    if (FAST) __syncthreads();  // s_lt visible (also when the evaluation has no multiplet chunk); near list consumed
+    if (FAST) __syncthreads();  // s_lt visible (also when the evaluation has no multiplet chunk); multiplet list consumed
     if (FARFIELD) {
         if (s_anyfar) {  // workgroup-uniform
-            // deterministic two-level sum of the 256 per-lane coefficient vectors (rows alias the near list)
+            // deterministic two-level sum of the 256 per-lane coefficient vectors (rows alias the multiplet list)
 #pragma unroll
             for (int k = 0; k < NC; k += 2) *(double2 *)&s_rows[tid * ROW + k] = make_double2(fcoef[k], fcoef[k + 1]);
             __syncthreads();
