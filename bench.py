@@ -39,7 +39,8 @@ def parse():
                     help="mh = adaptive random-walk MH + PT (what the reference runs); mala = Langevin drift, FD gradient")
     ap.add_argument("--engine", choices=["device", "host"], default="device",
                     help="device = whole MCMC iteration resident on the GPU; host = host-driven loop (one device call per step)")
-    ap.add_argument("--bins-per-thread", type=int, default=0, choices=[0, 1, 2, 4], help="tile = 256*K bins (0 = library default)")
+    ap.add_argument("--bins-per-thread", type=int, default=0, choices=[0, 1, 2, 4, 8, 16], help="tile = workgroup*K bins (0 = library default)")
+    ap.add_argument("--workgroup", type=int, default=0, choices=[0, 64, 256], help="workgroup size of the likelihood kernel (0 = library default)")
     ap.add_argument("--mala-steps", type=int, default=30, help="extra MALA-FD measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +102,7 @@ def main():
     lam = 1.3
     star = synth.make_c3_star(seed=20240229 + rank, nx=a.nx, step=2000.0 / a.nx)
     prec = pkg.PRECISION_FAST if a.precision == "fast" else pkg.PRECISION_STRICT
-    ctx = pkg.HipContext(local_rank, precision=prec, timing=True, bins_per_thread=a.bins_per_thread or None)
+    ctx = pkg.HipContext(local_rank, precision=prec, timing=True, bins_per_thread=a.bins_per_thread or None, workgroup=a.workgroup or None)
     # synthetic spectrum y = M(theta_true) * Exp(1): the model row comes from the GPU path itself (STRICT arithmetic)
     ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_STRICT)
     ctx.set_spectrum(star.x, np.ones_like(star.x))

@@ -20,7 +20,7 @@ OK = 0
 ERR_HIP, ERR_EMPTY_WINDOW, ERR_NAN_WINDOW, ERR_BAD_MODEL, ERR_BAD_ARG, ERR_NO_SPECTRUM, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
 MODEL_MS_GLOBAL_A1ETAA3_CLASSIC, MODEL_MS_LOCAL_BASIC, MODEL_MS_GLOBAL_AJ = 3, 11, 23
 PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_DIRECT = 0, 1, 2
-OPT_PRECISION, OPT_TIMING, OPT_BINS_PER_THREAD = 1, 2, 3
+OPT_PRECISION, OPT_TIMING, OPT_BINS_PER_THREAD, OPT_WORKGROUP = 1, 2, 3, 4
 
 
 class Multiplet(C.Structure):
@@ -112,7 +112,7 @@ def build_mode_table(model_id, params, plength, x):
 class HipContext:
     """One context = one GPU + one HIP stream + the resident spectrum (tamcmc_hip_ctx)."""
 
-    def __init__(self, device=0, precision=PRECISION_STRICT, timing=False, bins_per_thread=None):
+    def __init__(self, device=0, precision=PRECISION_STRICT, timing=False, bins_per_thread=None, workgroup=None):
         self._L = lib()
         h = _vp()
         st = self._L.tamcmc_hip_create(C.byref(h), int(device))
@@ -122,6 +122,8 @@ class HipContext:
         self.Nx = 0
         self.set_option(OPT_PRECISION, precision)
         self.set_option(OPT_TIMING, 1 if timing else 0)
+        if workgroup:
+            self.set_option(OPT_WORKGROUP, workgroup)
         if bins_per_thread:
             self.set_option(OPT_BINS_PER_THREAD, bins_per_thread)
 

@@ -62,11 +62,22 @@ int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
         if (value != TAMCMC_PRECISION_STRICT && value != TAMCMC_PRECISION_FAST && value != TAMCMC_PRECISION_FAST_DIRECT)
             return TAMCMC_ERR_BAD_ARG;
         c->precision = (int)value;
+        if (!c->geom_user_set) {  // measured best tile geometry per mode (tools/gpu_probe.py)
+            if (value == TAMCMC_PRECISION_FAST) { c->wgs = 64; c->K = 8; }   // far field: one wave per 512-bin tile
+            else { c->wgs = 256; c->K = 4; }                                  // per-bin loops: four waves per 1024-bin tile
+        }
         return TAMCMC_OK;
     case TAMCMC_OPT_TIMING: c->timing = value ? 1 : 0; return TAMCMC_OK;
     case TAMCMC_OPT_BINS_PER_THREAD:
-        if (value != 1 && value != 2 && value != 4) return TAMCMC_ERR_BAD_ARG;
+        if (!tamcmc::valid_geometry(c->wgs, (int)value)) return TAMCMC_ERR_BAD_ARG;
         c->K = (int)value;
+        c->geom_user_set = true;
+        return TAMCMC_OK;
+    case TAMCMC_OPT_WORKGROUP:  // sets the workgroup size AND its default bins per thread
+        if (value != 64 && value != 256) return TAMCMC_ERR_BAD_ARG;
+        c->wgs = (int)value;
+        c->K = (value == 64) ? 8 : 4;
+        c->geom_user_set = true;
         return TAMCMC_OK;
     default: return TAMCMC_ERR_BAD_ARG;
     }
@@ -93,7 +104,7 @@ int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *c, const double *x, const double *y,
 static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_stride, const double *Tcoefs, double p,
                       double *logL, double *model) {
     const int Nx = (int)c->Nx;
-    const int tb = tamcmc::tile_bins(c->K);
+    const int tb = tamcmc::tile_bins(c->wgs, c->K);
     const int ntiles = (Nx + tb - 1) / tb;
     HIPCHK(c, c->d_stage.reserve(L.bytes));
     HIPCHK(c, c->d_part.reserve((size_t)B * ntiles * 2));
@@ -115,7 +126,7 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     a.partials = c->d_part.p;
     a.model = model ? c->d_model.p : nullptr;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
-    HIPCHK(c, tamcmc::launch_loglike(a, c->precision, c->K, model != nullptr, st));
+    HIPCHK(c, tamcmc::launch_loglike(a, c->precision, c->wgs, c->K, model != nullptr, st));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, tamcmc::launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
     HIPCHK(c, hipMemcpyAsync(c->h_S.p, c->d_S.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -61,7 +61,9 @@ struct tamcmc_hip_ctx {
     // options
     int precision = TAMCMC_PRECISION_STRICT;
     int timing = 0;
-    int K = 4;  // bins per thread: tile = 1024 bins (measured best for both the direct and the far-field kernels)
+    int wgs = 256;  // workgroup size of k_loglike: 256 (4 waves per tile) or 64 (one wave per tile)
+    int K = 4;      // bins per thread: tile = wgs*K bins
+    bool geom_user_set = false;
     // resident spectrum
     int64_t Nx = 0;
     std::vector<double> hx;  // host copy of x (table builders need x[0], x[Nx-1], step)

@@ -508,7 +508,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     DCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t C = (size_t)a.C, Nv = (size_t)a.Nv;
-    const int tb = tile_bins(c->K);
+    const int tb = tile_bins(c->wgs, c->K);
     a.ntiles = (a.desc.Nx + tb - 1) / tb;
     DCHK(c->d_part.reserve(C * (size_t)a.ntiles * 2));
     a.partials = c->d_part.p;
@@ -542,7 +542,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             pending = 1;
             const bool timed = c->timing && (i % ev_every == 0) && used_ev < I.n_ev;
             if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
-            DCHK(launch_loglike(la, c->precision, c->K, false, st));
+            DCHK(launch_loglike(la, c->precision, c->wgs, c->K, false, st));
             if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
         } else {  // settle the last iteration of this run (MH test, swap, record, adaptation); nothing is proposed
             hipLaunchKernelGGL(k_iterate<false>, dim3(a.C), dim3(TB), lds, st, args, it, P, pending, rec, learn_p, I.adapt_scratch);

@@ -159,7 +159,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     HIPCHK(c, hipGetLastError());
 
     const int Nx = (int)c->Nx;
-    const int tbins = tile_bins(c->K);
+    const int tbins = tile_bins(c->wgs, c->K);
     const int ntiles = (Nx + tbins - 1) / tbins;
     HIPCHK(c, c->d_part.reserve((size_t)B * ntiles * 2));
     HIPCHK(c, c->d_S.reserve((size_t)B));
@@ -170,7 +170,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     a.mults = fa.T.mults; a.offsets = fa.T.pairs; a.noise = fa.T.noise; a.noise_stride = stride;
     a.nharvey = fa.T.nh; a.nnoise = fa.T.nn; a.partials = c->d_part.p; a.model = nullptr;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
-    HIPCHK(c, launch_loglike(a, c->precision, c->K, false, st));
+    HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, false, st));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
     HIPCHK(c, hipMemcpyAsync(c->h_S.p, c->d_S.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));

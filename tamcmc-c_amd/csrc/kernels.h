@@ -27,9 +27,10 @@ struct LoglikeArgs {
     double *model;                  // [B x Nx] or nullptr
 };
 
-int tile_bins(int K);
+int tile_bins(int wgs, int K);       // bins per workgroup = workgroup size x bins per thread
+bool valid_geometry(int wgs, int K);  // (256; 1,2,4) or (64; 4,8,16)
 // mode = TAMCMC_PRECISION_* (0 strict, 1 fast = far-field expansion + direct near field, 2 fast without the far field)
-hipError_t launch_loglike(LoglikeArgs a, int mode, int K, bool write_model, hipStream_t st);
+hipError_t launch_loglike(LoglikeArgs a, int mode, int wgs, int K, bool write_model, hipStream_t st);
 hipError_t launch_finalize(const double *partials, int B, int ntiles, double *S, hipStream_t st);
 
 }  // namespace tamcmc

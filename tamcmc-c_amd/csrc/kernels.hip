@@ -30,7 +30,7 @@ namespace tamcmc {
 
 namespace {
 
-constexpr int WG = 256;
+constexpr int WG = 256;  // k_finalize; k_loglike's workgroup size is a template parameter (256 = 4 waves, or 64 = one wave per tile)
 constexpr int CHUNK = 64;  // multiplets staged per pass: one wave compacts one chunk
 
 constexpr int F_FULL = 1;  // window covers every bin of the tile
@@ -76,7 +76,7 @@ __device__ __forceinline__ double rcp_nr2(double d) {
     return fma(fma(-d, r, 1.0), r, r);
 }
 
-template <int NV>
+template <int NV, int WGS = WG>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], double *s_red, double *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -93,7 +93,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double *s_red, dou
 #pragma unroll
         for (int i = 0; i < NV; i++) {
             double s = s_red[i];
-            for (int w = 1; w < WG / 64; w++) s = s + s_red[w * NV + i];
+            for (int w = 1; w < WGS / 64; w++) s = s + s_red[w * NV + i];
             out[i] = s;
         }
     }
@@ -220,12 +220,12 @@ __device__ __forceinline__ void mult_dispatch(const LdsMult &M, const double (&x
     }
 }
 
-template <int MODE, int K, bool WRITE_MODEL>
-__global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
+template <int MODE, int WGS, int K, bool WRITE_MODEL>
+__global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     constexpr bool FAST = (MODE != M_STRICT);
     constexpr bool FARFIELD = (MODE == M_FAST);
     // multiplet list and (after the multiplet loop) the coefficient-reduction rows share one LDS region
-    constexpr int LDS_BYTES = FARFIELD ? (WG * ROW * 8 > CHUNK * (int)sizeof(LdsMult) ? WG * ROW * 8 : CHUNK * (int)sizeof(LdsMult))
+    constexpr int LDS_BYTES = FARFIELD ? (WGS * ROW * 8 > CHUNK * (int)sizeof(LdsMult) ? WGS * ROW * 8 : CHUNK * (int)sizeof(LdsMult))
                                        : CHUNK * (int)sizeof(LdsMult);
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[LDS_BYTES];
     LdsMult *s_m = (LdsMult *)s_buf;
@@ -233,8 +233,8 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     __shared__ int s_n, s_nfar, s_anyfar;
     __shared__ int s_far[CHUNK];          // FARFIELD: positions (in s_m) of this chunk's far multiplets
     __shared__ double s_coef[NC];         // FARFIELD: the tile's far-field polynomial
-    __shared__ double s_part[16][NC];
-    __shared__ double s_red[2 * (WG / 64)];
+    __shared__ double s_part[WGS / 16][NC];
+    __shared__ double s_red[2 * (WGS / 64)];
     __shared__ double s_lt[TAMCMC_MAX_HARVEY];  // FAST: ln(1e-3*tau_k)
 
     // ---- XCD-aware block -> (tile, evaluation) ----
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     if (tile >= a.ntiles) return;  // whole workgroup leaves before any barrier
 
     const int tid = threadIdx.x;
-    constexpr int TILE = WG * K;
+    constexpr int TILE = WGS * K;
     const int t0 = tile * TILE;
     const int t1 = min(t0 + TILE, a.Nx);
 
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     int bin[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        bin[k] = t0 + k * WG + tid;
+        bin[k] = t0 + k * WGS + tid;
         const int bi = min(bin[k], a.Nx - 1);
         xv[k] = a.x[bi];
         acc[k] = 0.0;
@@ -272,19 +272,22 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     if (FAST && !harvey_poly) {
         if (tid < nh) s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
     }
-    double fcoef[NC];
     if (FARFIELD) {
-#pragma unroll
-        for (int k = 0; k < NC; k++) fcoef[k] = 0.0;
+        if (tid < NC) s_coef[tid] = 0.0;
         if (tid == 0) s_anyfar = harvey_poly ? 1 : 0;
+        __syncthreads();
         if (harvey_poly) {
-            // wave 1 (wave 0 is busy compacting the first chunk): lane = Harvey term, its NH coefficients go to that lane's fcoef
-            const int hl = tid - 64;
+            // lane = Harvey term (wave 1 when there are four waves: wave 0 is about to compact the first chunk); the NH
+            // series coefficients of the terms are added to the tile polynomial in term order by the last of these lanes
+            const int hl = (WGS > 64) ? tid - 64 : tid;
+            double f[NH];
+#pragma unroll
+            for (int k = 0; k < NH; k++) f[k] = 0.0;
             if (hl >= 0 && hl < nh) {
                 const double Hh = nz[3 * hl], tau = nz[3 * hl + 1], pw = nz[3 * hl + 2];
                 if (tau != 0.0) {
                     const double eps = h / xc;
-                    double u[NH], f[NH];
+                    double u[NH];
                     u[0] = exp(pw * log(1e-3 * tau * xc));
 #pragma unroll
                     for (int k = 0; k < NH - 1; k++) u[k + 1] = u[k] * eps * (pw - (double)k) / (double)(k + 1);
@@ -297,11 +300,18 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                         for (int jj = 1; jj <= k; jj++) acc2 = fma(u[jj], f[k - jj], acc2);
                         f[k] = -acc2 * iv0;
                     }
-#pragma unroll
-                    for (int k = 0; k < NH; k++) fcoef[k] = f[k];
                 }
             }
-            if (tid == 64 + TAMCMC_MAX_HARVEY) fcoef[0] = nz[nn - 1];  // white noise joins the constant term
+            // lanes hl = 0..nh-1 live in ONE wave: sum their series in lane order with shuffles, lane 0 adds the white noise
+            if (hl >= 0 && hl < 64) {
+#pragma unroll
+                for (int k = 0; k < NH; k++) {
+                    double v = f[k];
+                    double tot = 0.0;
+                    for (int t = 0; t < nh; t++) tot = tot + __shfl(v, t, 64);
+                    if (hl == 0) s_coef[k] = tot + (k == 0 ? nz[nn - 1] : 0.0);
+                }
+            }
         }
     }
 
@@ -376,10 +386,24 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
         }
         __syncthreads();
         const int n = s_n;
-        if (FARFIELD) {
-            // one lane per (far multiplet, m) slot: its NC Taylor coefficients, added to the lane's running vector
+        for (int q = 0; q < n; q++) {
+            const LdsMult &M = s_m[q];
+            if (FARFIELD && (M.flags & F_FAR)) continue;  // wave-uniform
+            switch (M.l) {  // wave-uniform
+            case 0: mult_dispatch<FAST, 1, K>(M, xv, bin, acc); break;
+            case 1: mult_dispatch<FAST, 3, K>(M, xv, bin, acc); break;
+            case 2: mult_dispatch<FAST, 5, K>(M, xv, bin, acc); break;
+            default: mult_dispatch<FAST, 7, K>(M, xv, bin, acc); break;
+            }
+        }
+        if (FARFIELD && s_nfar > 0) {  // workgroup-uniform
+            // AFTER the near-field loop (its registers are dead): one lane per (far multiplet, m) slot computes the NC Taylor
+            // coefficients of its component; the lanes' vectors are summed in a fixed order into the tile polynomial
+            double fcoef[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) fcoef[k] = 0.0;
             const int nslots = s_nfar * 7;
-            for (int slot = tid; slot < nslots; slot += WG) {
+            for (int slot = tid; slot < nslots; slot += WGS) {
                 const int jf = slot / 7, mm = slot - jf * 7;
                 const LdsMult &M = s_m[s_far[jf]];
                 if (mm < 2 * M.l + 1) {
@@ -417,22 +441,7 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
                     }
                 }
             }
-        }
-        for (int q = 0; q < n; q++) {
-            const LdsMult &M = s_m[q];
-            if (FARFIELD && (M.flags & F_FAR)) continue;  // wave-uniform
-            switch (M.l) {  // wave-uniform
-            case 0: mult_dispatch<FAST, 1, K>(M, xv, bin, acc); break;
-            case 1: mult_dispatch<FAST, 3, K>(M, xv, bin, acc); break;
-            case 2: mult_dispatch<FAST, 5, K>(M, xv, bin, acc); break;
-            default: mult_dispatch<FAST, 7, K>(M, xv, bin, acc); break;
-            }
-        }
-    }
-    if (FAST) __syncthreads();  // s_lt visible (also when the evaluation has no multiplet chunk); multiplet list consumed
-    if (FARFIELD) {
-        if (s_anyfar) {  // workgroup-uniform
-            // deterministic two-level sum of the 256 per-lane coefficient vectors (rows alias the multiplet list)
+            __syncthreads();  // every lane is done with the multiplet list: its LDS region now holds the reduction rows
 #pragma unroll
             for (int k = 0; k < NC; k += 2) *(double2 *)&s_rows[tid * ROW + k] = make_double2(fcoef[k], fcoef[k + 1]);
             __syncthreads();
@@ -445,12 +454,16 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
             }
             __syncthreads();
             if (tid < NC) {
-                double sum = 0.0;
+                double sum = s_coef[tid];
 #pragma unroll
-                for (int p = 0; p < 16; p++) sum = sum + s_part[p][tid];
+                for (int p = 0; p < WGS / 16; p++) sum = sum + s_part[p][tid];
                 s_coef[tid] = sum;
             }
-            __syncthreads();
+        }
+    }
+    if (FAST) __syncthreads();  // s_lt / s_coef visible (also when the evaluation has no multiplet chunk)
+    if (FARFIELD) {
+        if (s_anyfar) {  // workgroup-uniform: far multiplets and/or the background series
             const double inv_h = 1.0 / h;
 #pragma unroll
             for (int k = 0; k < K; k++) {
@@ -519,7 +532,7 @@ __global__ void __launch_bounds__(WG) k_loglike(const LoglikeArgs a) {
     }
     __syncthreads();
     double out[2];
-    block_reduce<2>(s, s_red, out);
+    block_reduce<2, WGS>(s, s_red, out);
     if (tid == 0) {
         double *p = a.partials + ((size_t)b * a.ntiles + tile) * 2;
         p[0] = out[0];
@@ -542,36 +555,48 @@ __global__ void __launch_bounds__(WG) k_finalize(const double *partials, int nti
     if (threadIdx.x == 0) S[b] = out[0] + out[1];
 }
 
-template <int MODE, int K>
+template <int MODE, int WGS, int K>
 void launch_k(const LoglikeArgs &a, bool write_model, int grid, hipStream_t st) {
-    if (write_model) hipLaunchKernelGGL((k_loglike<MODE, K, true>), dim3(grid), dim3(WG), 0, st, a);
-    else hipLaunchKernelGGL((k_loglike<MODE, K, false>), dim3(grid), dim3(WG), 0, st, a);
+    if (write_model) hipLaunchKernelGGL((k_loglike<MODE, WGS, K, true>), dim3(grid), dim3(WGS), 0, st, a);
+    else hipLaunchKernelGGL((k_loglike<MODE, WGS, K, false>), dim3(grid), dim3(WGS), 0, st, a);
+}
+
+template <int MODE>
+bool launch_geom(const LoglikeArgs &a, int wgs, int K, bool write_model, int grid, hipStream_t st) {
+    if (wgs == 256) {
+        if (K == 1) launch_k<MODE, 256, 1>(a, write_model, grid, st);
+        else if (K == 2) launch_k<MODE, 256, 2>(a, write_model, grid, st);
+        else if (K == 4) launch_k<MODE, 256, 4>(a, write_model, grid, st);
+        else return false;
+    } else if (wgs == 64) {  // one wave per tile: no cross-wave barrier, every wave stages / expands / reduces its own tile
+        if (K == 4) launch_k<MODE, 64, 4>(a, write_model, grid, st);
+        else if (K == 8) launch_k<MODE, 64, 8>(a, write_model, grid, st);
+        else if (K == 16) launch_k<MODE, 64, 16>(a, write_model, grid, st);
+        else return false;
+    } else return false;
+    return true;
 }
 
 }  // namespace
 
-int tile_bins(int K) { return WG * K; }
+int tile_bins(int wgs, int K) { return wgs * K; }
+bool valid_geometry(int wgs, int K) {
+    return (wgs == 256 && (K == 1 || K == 2 || K == 4)) || (wgs == 64 && (K == 4 || K == 8 || K == 16));
+}
 
-hipError_t launch_loglike(LoglikeArgs a, int mode, int K, bool write_model, hipStream_t st) {
+hipError_t launch_loglike(LoglikeArgs a, int mode, int wgs, int K, bool write_model, hipStream_t st) {
     if (a.B <= 0) return hipSuccess;
-    const int tb = WG * K;
+    if (!valid_geometry(wgs, K)) return hipErrorInvalidValue;
+    const int tb = wgs * K;
     a.ntiles = (a.Nx + tb - 1) / tb;
     const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
     const long long grid = (long long)ntiles_pad * a.B;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (mode == M_FAST) {
-        if (K == 1) launch_k<M_FAST, 1>(a, write_model, (int)grid, st);
-        else if (K == 2) launch_k<M_FAST, 2>(a, write_model, (int)grid, st);
-        else launch_k<M_FAST, 4>(a, write_model, (int)grid, st);
-    } else if (mode == M_FAST_DIRECT) {
-        if (K == 1) launch_k<M_FAST_DIRECT, 1>(a, write_model, (int)grid, st);
-        else if (K == 2) launch_k<M_FAST_DIRECT, 2>(a, write_model, (int)grid, st);
-        else launch_k<M_FAST_DIRECT, 4>(a, write_model, (int)grid, st);
-    } else {
-        if (K == 1) launch_k<M_STRICT, 1>(a, write_model, (int)grid, st);
-        else if (K == 2) launch_k<M_STRICT, 2>(a, write_model, (int)grid, st);
-        else launch_k<M_STRICT, 4>(a, write_model, (int)grid, st);
-    }
+    bool ok;
+    if (mode == M_FAST) ok = launch_geom<M_FAST>(a, wgs, K, write_model, (int)grid, st);
+    else if (mode == M_FAST_DIRECT) ok = launch_geom<M_FAST_DIRECT>(a, wgs, K, write_model, (int)grid, st);
+    else ok = launch_geom<M_STRICT>(a, wgs, K, write_model, (int)grid, st);
+    if (!ok) return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -19,9 +19,10 @@ T = 1.35 ** (np.arange(B) % 20)
 st, mults, _, _ = pkg.build_mode_table(star.model_id, star.params, star.plength, star.x)
 W = int(((mults["i1"] - mults["i0"]) * (2 * mults["l"] + 1)).sum())
 print("component-bin evals per model:", W, flush=True)
+GEOMS = [(256, 1), (256, 2), (256, 4), (64, 4), (64, 8), (64, 16)]
 for prec in (pkg.PRECISION_STRICT, pkg.PRECISION_FAST_DIRECT, pkg.PRECISION_FAST):
-    for K in (1, 2, 4):
-        c = pkg.HipContext(0, precision=prec, timing=True, bins_per_thread=K)
+    for wg, K in GEOMS:
+        c = pkg.HipContext(0, precision=prec, timing=True, workgroup=wg, bins_per_thread=K)
         c.set_spectrum(star.x, y)
         for _ in range(3):
             c.loglike_params_batch(star.model_id, P, star.plength, T)
@@ -35,6 +36,6 @@ for prec in (pkg.PRECISION_STRICT, pkg.PRECISION_FAST_DIRECT, pkg.PRECISION_FAST
             ref = logL.copy()
         ms, nl, ne = c.kernel_stats()
         k_us = ms / nl * 1e3
-        print(f"prec={prec} K={K} B={B}: kernel {k_us:9.1f} us  wall/call {wall*1e6:9.1f} us  "
+        print(f"prec={prec} wg={wg} K={K} B={B}: kernel {k_us:9.1f} us  wall/call {wall*1e6:9.1f} us  "
               f"comp-evals/s {W*B/(k_us*1e-6):.3e}  algGB/s {16*star.x.size*B/(k_us*1e-6)/1e9:.1f}  max|dlogL/logL| vs strict {np.max(np.abs(logL-ref)/np.abs(ref)):.2e}", flush=True)
         c.close()

@@ -7,14 +7,16 @@ import __graft_entry__ as g
 pkg = g.load_package()
 from tamcmc_c_amd import synth
 prec = pkg.PRECISION_FAST if (len(sys.argv) < 2 or sys.argv[1] == "fast") else pkg.PRECISION_STRICT
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 star = synth.make_c3_star()
-c = pkg.HipContext(0, precision=pkg.PRECISION_STRICT, bins_per_thread=K)
+c = pkg.HipContext(0, precision=pkg.PRECISION_STRICT)
 c.set_spectrum(star.x, np.ones_like(star.x))
 _, m0, _ = c.loglike_params_batch(star.model_id, star.params, star.plength, want_model=True)
 y = star.set_spectrum_from_model(m0[0], 1)
 c.set_option(pkg.OPT_PRECISION, prec)
+if K:
+    c.set_option(pkg.OPT_BINS_PER_THREAD, K)
 c.set_spectrum(star.x, y)
 rng = np.random.default_rng(0)
 B = 20
