@@ -19,7 +19,7 @@ T = 1.35 ** (np.arange(B) % 20)
 st, mults, _, _ = pkg.build_mode_table(star.model_id, star.params, star.plength, star.x)
 W = int(((mults["i1"] - mults["i0"]) * (2 * mults["l"] + 1)).sum())
 print("component-bin evals per model:", W, flush=True)
-GEOMS = [(256, 1), (256, 2), (256, 4), (64, 4), (64, 8), (64, 16)]
+GEOMS = [(256, 4), (64, 8)] if B != 20 else [(256, 1), (256, 2), (256, 4), (64, 4), (64, 8), (64, 16)]
 for prec in (pkg.PRECISION_STRICT, pkg.PRECISION_FAST_DIRECT, pkg.PRECISION_FAST):
     for wg, K in GEOMS:
         c = pkg.HipContext(0, precision=prec, timing=True, workgroup=wg, bins_per_thread=K)
