@@ -32,9 +32,13 @@ def _perturbed(star, B, rng, scale=0.01):
     return P
 
 
+GEOMS = [(256, 1), (256, 2), (256, 4), (64, 4), (64, 8), (64, 16)]   # (workgroup size, bins per thread)
+
+
 @pytest.mark.parametrize("seed", range(4))
-@pytest.mark.parametrize("K", [1, 2, 4])
-def test_reference_recipe_strict_bit_exact(pkg, oracle, synth, ctxs, seed, K):
+@pytest.mark.parametrize("geom", GEOMS)
+def test_reference_recipe_strict_bit_exact(pkg, oracle, synth, ctxs, seed, geom):
+    wg, K = geom
     rng = np.random.default_rng(200 + seed)
     lmax = int(rng.integers(2, 4))
     p, pl = synth.make_params_aj_model(rng, lmax=lmax, nfreqs=5, dnu=rng.uniform(129, 130), epsilon=rng.uniform(0, 0.05),
@@ -44,6 +48,7 @@ def test_reference_recipe_strict_bit_exact(pkg, oracle, synth, ctxs, seed, K):
     st, m_o = oracle.call_model(23, p, pl, x)
     y = m_o * np.random.default_rng(seed).exponential(1.0, nx)
     c = ctxs["strict"]
+    c.set_option(pkg.OPT_WORKGROUP, wg)
     c.set_option(pkg.OPT_BINS_PER_THREAD, K)
     c.set_spectrum(x, y)
     logL, model, status = c.loglike_params_batch(23, p, pl, want_model=True)
@@ -54,6 +59,7 @@ def test_reference_recipe_strict_bit_exact(pkg, oracle, synth, ctxs, seed, K):
     assert np.linalg.norm(model[0] - m_o) <= 1e-8
     for name in ("fast", "fast_direct"):
         f = ctxs[name]
+        f.set_option(pkg.OPT_WORKGROUP, wg)
         f.set_option(pkg.OPT_BINS_PER_THREAD, K)
         f.set_spectrum(x, y)
         logLf, modelf, _ = f.loglike_params_batch(23, p, pl, want_model=True)
@@ -72,6 +78,7 @@ def test_c2_local_batch_tempered(pkg, oracle, synth, ctxs):
     ref, m_o, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T, want_model=True)
     for name, tol_m, tol_l in (("strict", 0.0, 1e-12), ("fast", 1e-12, 1e-11), ("fast_direct", 1e-12, 1e-11)):
         c = ctxs[name]
+        c.set_option(pkg.OPT_WORKGROUP, 256)
         c.set_option(pkg.OPT_BINS_PER_THREAD, 2)
         c.set_spectrum(star.x, y)
         logL, model, status = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0, want_model=True)
@@ -186,7 +193,8 @@ def test_full_size_c3_properties(pkg, oracle, synth, ctxs):
     out = {}
     for name in ("strict", "fast", "fast_direct"):
         c = ctxs[name]
-        c.set_option(pkg.OPT_BINS_PER_THREAD, 2)
+        c.set_option(pkg.OPT_WORKGROUP, 64 if name == "fast" else 256)   # the library defaults of each mode
+        c.set_option(pkg.OPT_BINS_PER_THREAD, 8 if name == "fast" else 4)
         c.set_spectrum(star.x, y)
         logL, _, status = c.loglike_params_batch(star.model_id, P, star.plength, T, 1.0)
         logL1, _, _ = c.loglike_params_batch(star.model_id, P, star.plength, None, 1.0)
