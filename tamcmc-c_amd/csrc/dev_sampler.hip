@@ -528,6 +528,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     la.x0 = a.desc.x_first; la.step = a.desc.step;
     la.mults = a.mults; la.offsets = a.pairs; la.noise = a.noise; la.noise_stride = a.desc.stride;
     la.nharvey = a.nh; la.nnoise = a.nn; la.partials = a.partials; la.model = nullptr;
+    la.dbg = a.dbg ? a.dbg + 8 : nullptr;
     int used_ev = 0;
     const long ev_every = n_iter > 64 ? n_iter / 64 : 1;
     int P = I.parity, pending = 0;
@@ -551,11 +552,14 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     }
     I.parity = P;
     if (a.dbg) {  // phase stamps of the last k_iterate<true> launch (100 MHz wall clock), workgroup 0
-        long h[8];
+        long h[16];
         DCHK(hipMemcpyAsync(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost, st));
         DCHK(hipStreamSynchronize(st));
         fprintf(stderr, "[k_iterate stamps us] settle %.2f | rng+matvec %.2f | scatter+prior %.2f | unpack %.2f\n",
                 (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[4] - h[2]) * 0.01, (h[6] - h[4]) * 0.01);
+        const long *k = h + 8;
+        fprintf(stderr, "[k_loglike stamps us, middle tile] prologue %.2f | staging %.2f | near %.2f | far+reduce %.2f | horner %.2f | epilogue %.2f\n",
+                (k[1] - k[0]) * 0.01, (k[2] - k[1]) * 0.01, (k[3] - k[2]) * 0.01, (k[4] - k[3]) * 0.01, (k[5] - k[4]) * 0.01, (k[6] - k[5]) * 0.01);
     }
     DCHK(hipGetLastError());
     if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));

@@ -25,6 +25,7 @@ struct LoglikeArgs {
     const int32_t *nnoise;          // [B]
     double *partials;               // [B x ntiles x 2]
     double *model;                  // [B x Nx] or nullptr
+    long *dbg = nullptr;            // optional phase stamps of one workgroup (TAMCMC_DEBUG_STAMPS)
 };
 
 int tile_bins(int wgs, int K);       // bins per workgroup = workgroup size x bins per thread

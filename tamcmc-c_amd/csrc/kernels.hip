@@ -187,6 +187,7 @@ __device__ __forceinline__ void fast_mult(const LdsMult &M, const double (&xv)[K
                 }
                 acc[k] = acc[k] + res;
             }
+            if (K > 4 && (k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live ranges: four bins in flight
         }
     } else {  // denominators too large to multiply on this tile: plain sum (never taken for sane widths)
 #pragma unroll
@@ -246,6 +247,8 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     if (tile >= a.ntiles) return;  // whole workgroup leaves before any barrier
 
     const int tid = threadIdx.x;
+#define KSTAMP(k) do { if (a.dbg && b == 0 && tile == a.ntiles / 2 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
+    KSTAMP(0);
     constexpr int TILE = WGS * K;
     const int t0 = tile * TILE;
     const int t1 = min(t0 + TILE, a.Nx);
@@ -290,8 +293,8 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                     double u[NH];
                     u[0] = exp(pw * log(1e-3 * tau * xc));
 #pragma unroll
-                    for (int k = 0; k < NH - 1; k++) u[k + 1] = u[k] * eps * (pw - (double)k) / (double)(k + 1);
-                    const double iv0 = 1.0 / (1.0 + u[0]);
+                    for (int k = 0; k < NH - 1; k++) u[k + 1] = u[k] * eps * (pw - (double)k) * (1.0 / (double)(k + 1));
+                    const double iv0 = rcp_nr2(1.0 + u[0]);
                     f[0] = Hh * iv0;
 #pragma unroll
                     for (int k = 1; k < NH; k++) {
@@ -316,6 +319,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     }
 
     const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
+    KSTAMP(1);
     for (int c0 = mbeg; c0 < mend; c0 += CHUNK) {
         __syncthreads();  // previous chunk fully consumed
         if (tid < 64) {
@@ -385,6 +389,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             if (tid == 0) s_n = __popcll(mask);
         }
         __syncthreads();
+        KSTAMP(2);
         const int n = s_n;
         for (int q = 0; q < n; q++) {
             const LdsMult &M = s_m[q];
@@ -396,6 +401,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             default: mult_dispatch<FAST, 7, K>(M, xv, bin, acc); break;
             }
         }
+        KSTAMP(3);
         if (FARFIELD && s_nfar > 0) {  // workgroup-uniform
             // AFTER the near-field loop (its registers are dead): one lane per (far multiplet, m) slot computes the NC Taylor
             // coefficients of its component; the lanes' vectors are summed in a fixed order into the tile polynomial
@@ -461,6 +467,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             }
         }
     }
+    KSTAMP(4);
     if (FAST) __syncthreads();  // s_lt / s_coef visible (also when the evaluation has no multiplet chunk)
     if (FARFIELD) {
         if (s_anyfar) {  // workgroup-uniform: far multiplets and/or the background series
@@ -476,6 +483,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         }
     }
 
+    KSTAMP(5);
     // ---- background + likelihood terms ----
     double s[2] = {0.0, 0.0};
     const double white = nz[nn - 1];
@@ -538,6 +546,8 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         p[0] = out[0];
         p[1] = out[1];
     }
+    KSTAMP(6);
+#undef KSTAMP
 }
 
 // One workgroup per evaluation: fixed-order sum of the per-tile partials -> S[b] = sum1 + sum2.
