@@ -54,6 +54,8 @@ extern "C" {
 #define TAMCMC_OPT_PRECISION 1   /* value: TAMCMC_PRECISION_* (default STRICT) */
 #define TAMCMC_OPT_TIMING 2      /* value: 0/1 -- bracket the likelihood kernel with HIP events on the context stream */
 #define TAMCMC_OPT_BINS_PER_THREAD 3 /* value: 1,2,4 (workgroup 256) or 4,8,16 (workgroup 64) -- tile = workgroup*value bins */
+#define TAMCMC_OPT_FD_WINDOWED 5     /* value: 0/1 -- FAST modes: FD gradients from delta tables (only the multiplets a perturbation
+                                        changes, on their windows, against the stored base model row); default 1 */
 #define TAMCMC_OPT_WORKGROUP 4       /* value: 256 (four waves share a tile) or 64 (one wave per tile); resets bins per thread */
 
 /* One (n,l) multiplet: <=7 Lorentzian m-components on its truncation window.

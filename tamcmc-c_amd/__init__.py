@@ -20,7 +20,7 @@ OK = 0
 ERR_HIP, ERR_EMPTY_WINDOW, ERR_NAN_WINDOW, ERR_BAD_MODEL, ERR_BAD_ARG, ERR_NO_SPECTRUM, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
 MODEL_MS_GLOBAL_A1ETAA3_CLASSIC, MODEL_MS_LOCAL_BASIC, MODEL_MS_GLOBAL_AJ = 3, 11, 23
 PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_DIRECT = 0, 1, 2
-OPT_PRECISION, OPT_TIMING, OPT_BINS_PER_THREAD, OPT_WORKGROUP = 1, 2, 3, 4
+OPT_PRECISION, OPT_TIMING, OPT_BINS_PER_THREAD, OPT_WORKGROUP, OPT_FD_WINDOWED = 1, 2, 3, 4, 5
 
 
 class Multiplet(C.Structure):

@@ -73,6 +73,7 @@ int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
         c->K = (int)value;
         c->geom_user_set = true;
         return TAMCMC_OK;
+    case TAMCMC_OPT_FD_WINDOWED: c->fd_windowed = value ? 1 : 0; return TAMCMC_OK;
     case TAMCMC_OPT_WORKGROUP:  // sets the workgroup size AND its default bins per thread
         if (value != 64 && value != 256) return TAMCMC_ERR_BAD_ARG;
         c->wgs = (int)value;

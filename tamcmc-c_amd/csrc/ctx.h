@@ -64,6 +64,7 @@ struct tamcmc_hip_ctx {
     int wgs = 256;  // workgroup size of k_loglike: 256 (4 waves per tile) or 64 (one wave per tile)
     int K = 4;      // bins per thread: tile = wgs*K bins
     bool geom_user_set = false;
+    int fd_windowed = 1;  // FAST modes: finite differences through delta tables (changed multiplets on their windows only)
     // resident spectrum
     int64_t Nx = 0;
     std::vector<double> hx;  // host copy of x (table builders need x[0], x[Nx-1], step)

@@ -35,6 +35,13 @@ struct FdArgs {
     double *logPr_plus;    // [C x E] log-prior at the evaluation point (e=0: the base point)
     double *logPr_minus;   // [C x E] log-prior at theta - h e_k (e>=1)
     int *status;           // [C x E]
+    // windowed mode (delta tables): rows [B*per, 2B*per) of T.mults hold each block's copy of the BASE table,
+    // D is the delta launch's input block (2*per rows per evaluation: +new / -old of the changed multiplets)
+    int windowed;
+    TablePtrs D;
+    int *d_range, *d_flags, *d_row;
+    double *d_noise_old;
+    TablePtrs Bs;          // base launch (C evaluations): ranges / counts / noise rows indexed by chain
 };
 
 __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
@@ -43,8 +50,19 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
     double *s_params = (double *)s_raw;
     const UnpackLds U = carve_unpack_lds((unsigned char *)(s_params + Np));
     const int slot = blockIdx.x, c = slot / a.E, e = slot - c * a.E, tid = threadIdx.x;
+    const int B = a.C * a.E, per = a.desc.per;
+    __shared__ int s_lo, s_hi, s_nchg, s_noise_chg, s_base_status;
     for (int i = tid; i < Np; i += FB) s_params[i] = a.params[(size_t)c * Np + i];
     unpack_begin(a.desc, U);
+    if (a.windowed && e > 0) {
+        // this block's own copy of the BASE table (slot B+slot): the changed rows are found by comparing with it
+        if (tid == FB - 1) mt::shared_scalars_base(a.desc.model_id, s_params, a.desc.plength, *U.S);
+        __syncthreads();
+        wg_unpack(a.desc, s_params, U, B + slot, a.T, true);
+        __syncthreads();
+        if (tid == 0) { s_base_status = *U.status; *U.status = TAMCMC_OK; *U.reject = 0; }
+        __syncthreads();
+    }
     double lp_minus = 0.0;
     const bool with_prior = a.desc.prior_class != 0;
     if (e > 0) {
@@ -74,6 +92,65 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
         a.logPr_plus[slot] = lp;
         a.logPr_minus[slot] = lp_minus;
         a.status[slot] = *U.status;
+    }
+    if (!a.windowed) return;
+    __syncthreads();
+    const int stride = a.desc.stride;
+    if (e == 0) {
+        // base evaluation of chain c: the base launch (B = C, model rows written) reads the SAME table rows
+        if (tid == 0) {
+            a.Bs.pairs[2 * c] = a.T.pairs[2 * slot];
+            a.Bs.pairs[2 * c + 1] = a.T.pairs[2 * slot + 1];
+            a.Bs.nh[c] = a.T.nh[slot];
+            a.Bs.nn[c] = a.T.nn[slot];
+            // no delta work for this slot
+            a.D.pairs[2 * slot] = 0; a.D.pairs[2 * slot + 1] = 0; a.D.nh[slot] = 0; a.D.nn[slot] = 1;
+            a.d_range[2 * slot] = 0; a.d_range[2 * slot + 1] = 0; a.d_flags[slot] = 0; a.d_row[slot] = c;
+        }
+        for (int i = tid; i < stride; i += FB) a.Bs.noise[(size_t)c * stride + i] = a.T.noise[(size_t)slot * stride + i];
+        return;
+    }
+    // ---- delta table: the multiplets whose row differs from the base row, +new / -old, and the affected bin range ----
+    if (tid == 0) { s_lo = a.desc.Nx; s_hi = 0; s_nchg = 0; s_noise_chg = 0; }
+    __syncthreads();
+    const bool ok = (a.status[slot] == TAMCMC_OK) && (s_base_status == TAMCMC_OK);
+    tamcmc_multiplet *drows = a.D.mults + (size_t)slot * 2 * per;
+    for (int j0 = 0; j0 < per; j0 += FB) {
+        const int jdx = j0 + tid;
+        bool chg = false;
+        if (ok && jdx < per) {
+            const unsigned long long *pn = (const unsigned long long *)&a.T.mults[(size_t)slot * per + jdx];
+            const unsigned long long *po = (const unsigned long long *)&a.T.mults[(size_t)(B + slot) * per + jdx];
+            for (int w = 0; w < (int)(sizeof(tamcmc_multiplet) / 8); w++) chg = chg || (pn[w] != po[w]);
+        }
+        if (chg) {
+            const int pos = atomicAdd(&s_nchg, 1);   // order of the changed rows is irrelevant (a sum)
+            const tamcmc_multiplet &rn = a.T.mults[(size_t)slot * per + jdx];
+            tamcmc_multiplet ro = a.T.mults[(size_t)(B + slot) * per + jdx];
+            for (int m = 0; m < 7; m++) ro.hv[m] = -ro.hv[m];
+            drows[2 * pos] = rn;
+            drows[2 * pos + 1] = ro;
+            atomicMin(&s_lo, min(rn.i0, ro.i0));
+            atomicMax(&s_hi, max(rn.i1, ro.i1));
+        }
+    }
+    for (int i = tid; i < stride; i += FB) {
+        const double vn = a.T.noise[(size_t)slot * stride + i], vo = a.T.noise[(size_t)(B + slot) * stride + i];
+        a.D.noise[(size_t)slot * stride + i] = vn;
+        a.d_noise_old[(size_t)slot * stride + i] = vo;
+        if (ok && i < a.T.nn[slot] && vn != vo) s_noise_chg = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int n = s_nchg;
+        a.D.pairs[2 * slot] = slot * 2 * per;
+        a.D.pairs[2 * slot + 1] = slot * 2 * per + 2 * n;
+        a.D.nh[slot] = a.T.nh[slot];
+        a.D.nn[slot] = a.T.nn[slot];
+        a.d_flags[slot] = s_noise_chg;
+        a.d_row[slot] = c;
+        a.d_range[2 * slot] = s_noise_chg ? 0 : (n ? s_lo : 0);
+        a.d_range[2 * slot + 1] = s_noise_chg ? a.desc.Nx : (n ? s_hi : 0);
     }
 }
 
@@ -126,8 +203,23 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     const size_t o_lpm = o; o = al(o + (size_t)B * 8);
     const size_t o_st = o; o = al(o + (size_t)B * 4);
     const size_t out_bytes = o - in_bytes;
-    const StageLayout L(B, stride, (size_t)B * per);
+    // windowed finite differences (FAST modes): only the multiplets a perturbation changes are re-evaluated, on their
+    // windows, against the stored base model row ("the main algorithmic lever")
+    const bool windowed = c->fd_windowed && c->precision != TAMCMC_PRECISION_STRICT && delta_geometry(c->wgs, c->K) && Nvars > 0;
+    const int nslots = windowed ? 2 * B : B;                   // windowed: slots [B, 2B) = per-block copies of the base table
+    const StageLayout L(nslots, stride, (size_t)nslots * per);
     const size_t o_tab = o; o = al(o + L.bytes);
+    const StageLayout LD(B, stride, (size_t)B * 2 * per);      // delta launch input block
+    const StageLayout LB(C, stride, 0);                        // base launch: ranges / counts / noise rows by chain
+    size_t o_dtab = 0, o_btab = 0, o_drange = 0, o_dflags = 0, o_drow = 0, o_dnold = 0;
+    if (windowed) {
+        o_dtab = o; o = al(o + LD.bytes);
+        o_btab = o; o = al(o + LB.bytes);
+        o_drange = o; o = al(o + (size_t)2 * B * 4);
+        o_dflags = o; o = al(o + (size_t)B * 4);
+        o_drow = o; o = al(o + (size_t)B * 4);
+        o_dnold = o; o = al(o + (size_t)B * stride * 8);
+    }
     HIPCHK(c, c->h_fd.reserve(in_bytes + out_bytes));
     HIPCHK(c, c->d_fd.reserve(o));
     unsigned char *hb = c->h_fd.p, *db = c->d_fd.p;
@@ -142,18 +234,31 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     std::memcpy(hb + o_idx, index_to_relax, Nv * 4);
     HIPCHK(c, hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
 
+    auto table_ptrs = [](unsigned char *base, const StageLayout &Lx) {
+        TablePtrs T;
+        T.mults = (tamcmc_multiplet *)(base + Lx.off_mults); T.pairs = (int *)(base + Lx.off_pairs);
+        T.nh = (int *)(base + Lx.off_nh); T.nn = (int *)(base + Lx.off_nn); T.noise = (double *)(base + Lx.off_noise);
+        return T;
+    };
     FdArgs fa;
     fa.desc.model_id = model_id; fa.desc.prior_class = prior_class; fa.desc.Np = (int)Nparams; fa.desc.per = per;
     fa.desc.stride = stride; fa.desc.Nx = (int)c->Nx;
     fa.desc.x_first = c->hx[0]; fa.desc.x_last = c->hx[(size_t)c->Nx - 1]; fa.desc.step = c->hx[1] - c->hx[0];
     fa.desc.plength = (const int *)(db + o_pl); fa.desc.priors_switch = (const int *)(db + o_sw);
     fa.desc.priors = (const double *)(db + o_pr); fa.desc.extra = (const double *)(db + o_ex); fa.desc.poly = c->d_poly.p;
-    unsigned char *tb = db + o_tab;
-    fa.T.mults = (tamcmc_multiplet *)(tb + L.off_mults); fa.T.pairs = (int *)(tb + L.off_pairs);
-    fa.T.nh = (int *)(tb + L.off_nh); fa.T.nn = (int *)(tb + L.off_nn); fa.T.noise = (double *)(tb + L.off_noise);
+    fa.T = table_ptrs(db + o_tab, L);
     fa.C = C; fa.E = E; fa.Nv = Nvars;
     fa.params = (const double *)(db + o_params); fa.idx = (const int *)(db + o_idx); fa.h = (const double *)(db + o_h);
     fa.logPr_plus = (double *)(db + o_lpp); fa.logPr_minus = (double *)(db + o_lpm); fa.status = (int *)(db + o_st);
+    fa.windowed = windowed ? 1 : 0;
+    fa.D = fa.T; fa.Bs = fa.T;
+    fa.d_range = nullptr; fa.d_flags = nullptr; fa.d_row = nullptr; fa.d_noise_old = nullptr;
+    if (windowed) {
+        fa.D = table_ptrs(db + o_dtab, LD);
+        fa.Bs = table_ptrs(db + o_btab, LB);
+        fa.d_range = (int *)(db + o_drange); fa.d_flags = (int *)(db + o_dflags); fa.d_row = (int *)(db + o_drow);
+        fa.d_noise_old = (double *)(db + o_dnold);
+    }
     const size_t lds = Np * 8 + unpack_lds_bytes() + 32;
     hipLaunchKernelGGL(k_fd_unpack, dim3(B), dim3(FB), lds, st, fa);
     HIPCHK(c, hipGetLastError());
@@ -161,19 +266,40 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     const int Nx = (int)c->Nx;
     const int tbins = tile_bins(c->wgs, c->K);
     const int ntiles = (Nx + tbins - 1) / tbins;
-    HIPCHK(c, c->d_part.reserve((size_t)B * ntiles * 2));
-    HIPCHK(c, c->d_S.reserve((size_t)B));
-    HIPCHK(c, c->h_S.reserve((size_t)B));
+    const size_t nS = windowed ? (size_t)C + B : (size_t)B;
+    HIPCHK(c, c->d_part.reserve(nS * ntiles * 2));
+    HIPCHK(c, c->d_S.reserve(nS));
+    HIPCHK(c, c->h_S.reserve(nS));
     LoglikeArgs a;
-    a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.B = B; a.ntiles = ntiles;
+    a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.ntiles = ntiles;
     a.x0 = c->hx[0]; a.step = c->hx[1] - c->hx[0];
-    a.mults = fa.T.mults; a.offsets = fa.T.pairs; a.noise = fa.T.noise; a.noise_stride = stride;
-    a.nharvey = fa.T.nh; a.nnoise = fa.T.nn; a.partials = c->d_part.p; a.model = nullptr;
+    a.noise_stride = stride; a.model = nullptr;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
-    HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, false, st));
+    if (!windowed) {
+        a.B = B;
+        a.mults = fa.T.mults; a.offsets = fa.T.pairs; a.noise = fa.T.noise; a.nharvey = fa.T.nh; a.nnoise = fa.T.nn;
+        a.partials = c->d_part.p;
+        HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, false, st));
+        HIPCHK(c, launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
+    } else {
+        // (1) the C base points: full evaluation, model rows kept
+        HIPCHK(c, c->d_model.reserve((size_t)C * Nx));
+        a.B = C;
+        a.mults = fa.T.mults; a.offsets = fa.Bs.pairs; a.noise = fa.Bs.noise; a.nharvey = fa.Bs.nh; a.nnoise = fa.Bs.nn;
+        a.partials = c->d_part.p; a.model = c->d_model.p;
+        HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, true, st));
+        HIPCHK(c, launch_finalize(c->d_part.p, C, ntiles, c->d_S.p, st));
+        // (2) the C*Nvars perturbed points: log-likelihood DIFFERENCES from the delta tables
+        LoglikeArgs d = a;
+        d.B = B; d.model = nullptr;
+        d.mults = fa.D.mults; d.offsets = fa.D.pairs; d.noise = fa.D.noise; d.nharvey = fa.D.nh; d.nnoise = fa.D.nn;
+        d.partials = c->d_part.p + (size_t)C * ntiles * 2;
+        d.d_range = fa.d_range; d.d_flags = fa.d_flags; d.d_row = fa.d_row; d.d_noise_old = fa.d_noise_old; d.model0 = c->d_model.p;
+        HIPCHK(c, launch_loglike_delta(d, c->precision, c->wgs, c->K, st));
+        HIPCHK(c, launch_finalize(d.partials, B, ntiles, c->d_S.p + C, st));
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));
-    HIPCHK(c, launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_S.p, c->d_S.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_S.p, c->d_S.p, nS * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(hb + in_bytes, db + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     if (c->timing) {
@@ -189,14 +315,23 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     int first_err = TAMCMC_OK;
     for (int ch = 0; ch < C; ch++) {
         const double T = Tcoefs ? Tcoefs[ch] : 1.0;
-        auto logL_of = [&](int e) {
-            const size_t s = (size_t)ch * E + e;
-            if (stt[s] != TAMCMC_OK) { if (first_err == TAMCMC_OK) first_err = stt[s]; return (double)NAN; }
-            long double f = c->h_S.p[s];
+        // S of evaluation e: full sums (non-windowed) or base sum + difference (windowed)
+        auto scaled = [&](double S) {
+            long double f = S;
             f = -pl * f;
             return (double)(f / T);
         };
-        const double L0 = logL_of(0);
+        auto failed = [&](int e) {
+            const size_t s = (size_t)ch * E + e;
+            if (stt[s] != TAMCMC_OK) { if (first_err == TAMCMC_OK) first_err = stt[s]; return true; }
+            return false;
+        };
+        const double L0 = failed(0) ? (double)NAN : scaled(windowed ? c->h_S.p[ch] : c->h_S.p[(size_t)ch * E]);
+        auto dlogL_of = [&](int e) {  // logL(theta + h e_k) - logL(theta)
+            if (failed(e)) return (double)NAN;
+            if (windowed) return scaled(c->h_S.p[(size_t)C + (size_t)ch * E + e]);
+            return scaled(c->h_S.p[(size_t)ch * E + e]) - L0;
+        };
         logL0[ch] = L0;
         if (logPr0) logPr0[ch] = lpp[(size_t)ch * E];
         const double pr0 = lpp[(size_t)ch * E];
@@ -204,7 +339,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
             const double x0 = params[(size_t)ch * Np + index_to_relax[k]];
             volatile double xp = x0 + hstep[k];
             const double happ = xp - x0;  // the step actually applied (the device adds the same two doubles)
-            double g = (logL_of(k + 1) - L0) / happ;
+            double g = dlogL_of(k + 1) / happ;
             if (prior_class != 0) {
                 if (!std::isfinite(g)) g = 0.0;
                 const double prp = lpp[(size_t)ch * E + k + 1], prm = lpm[(size_t)ch * E + k + 1];

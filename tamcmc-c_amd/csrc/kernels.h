@@ -26,12 +26,23 @@ struct LoglikeArgs {
     double *partials;               // [B x ntiles x 2]
     double *model;                  // [B x Nx] or nullptr
     long *dbg = nullptr;            // optional phase stamps of one workgroup (TAMCMC_DEBUG_STAMPS)
+    // DELTA launches (windowed finite differences, fd_batch.hip): evaluation b's table holds the CHANGED multiplets only,
+    // new rows with +H*V and old rows with -H*V, so the kernel accumulates dM = M(theta + h e_k) - M(theta); the partial
+    // sums are those of the log-likelihood DIFFERENCE against the base model row, over the affected bins only.
+    const int32_t *d_range = nullptr;     // [2B] affected bin range [lo, hi) of evaluation b
+    const int32_t *d_flags = nullptr;     // [B]  bit 0: the noise parameters changed (background difference on every bin)
+    const double *d_noise_old = nullptr;  // [B x noise_stride] |noise params| of the base point
+    const int32_t *d_row = nullptr;       // [B]  row of model0 holding the base model of evaluation b
+    const double *model0 = nullptr;       // [rows x Nx] base model rows
 };
 
 int tile_bins(int wgs, int K);       // bins per workgroup = workgroup size x bins per thread
 bool valid_geometry(int wgs, int K);  // (256; 1,2,4) or (64; 4,8,16)
+bool delta_geometry(int wgs, int K);  // geometries the DELTA variant is instantiated for: (256,4), (64,8)
 // mode = TAMCMC_PRECISION_* (0 strict, 1 fast = far-field expansion + direct near field, 2 fast without the far field)
 hipError_t launch_loglike(LoglikeArgs a, int mode, int wgs, int K, bool write_model, hipStream_t st);
+// DELTA variant (FAST modes only): a.d_* / a.model0 must be set
+hipError_t launch_loglike_delta(LoglikeArgs a, int mode, int wgs, int K, hipStream_t st);
 hipError_t launch_finalize(const double *partials, int B, int ntiles, double *S, hipStream_t st);
 
 }  // namespace tamcmc

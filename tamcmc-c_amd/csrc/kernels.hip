@@ -221,9 +221,10 @@ __device__ __forceinline__ void mult_dispatch(const LdsMult &M, const double (&x
     }
 }
 
-template <int MODE, int WGS, int K, bool WRITE_MODEL>
+template <int MODE, int WGS, int K, bool WRITE_MODEL, bool DELTA = false>
 __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     constexpr bool FAST = (MODE != M_STRICT);
+    static_assert(!DELTA || (FAST && !WRITE_MODEL), "DELTA launches are FAST-mode, logL-only");
     constexpr bool FARFIELD = (MODE == M_FAST);
     // multiplet list and (after the multiplet loop) the coefficient-reduction rows share one LDS region
     constexpr int LDS_BYTES = FARFIELD ? (WGS * ROW * 8 > CHUNK * (int)sizeof(LdsMult) ? WGS * ROW * 8 : CHUNK * (int)sizeof(LdsMult))
@@ -252,6 +253,17 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     constexpr int TILE = WGS * K;
     const int t0 = tile * TILE;
     const int t1 = min(t0 + TILE, a.Nx);
+    if (DELTA) {  // tiles outside the affected bin range contribute exactly 0 (workgroup-uniform exit before any barrier)
+        const int lo = a.d_range[2 * b], hi = a.d_range[2 * b + 1];
+        if (t1 <= lo || t0 >= hi) {
+            if (tid == 0) {
+                double *p = a.partials + ((size_t)b * a.ntiles + tile) * 2;
+                p[0] = 0.0;
+                p[1] = 0.0;
+            }
+            return;
+        }
+    }
 
     double xv[K], acc[K];
     int bin[K];
@@ -266,14 +278,21 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     const double *nz = a.noise + (size_t)b * a.noise_stride;
     const int nh = a.nharvey[b];
     const int nn = a.nnoise[b];
+    // DELTA: background difference only when the noise parameters changed (same Harvey count on both sides)
+    const bool bg = !DELTA || (a.d_flags[b] & 1);
+    const double *nzo = DELTA ? a.d_noise_old + (size_t)b * a.noise_stride : nz;
     // tile geometry for the far field: centre and half-width of the nominal tile on the regular grid
     const double h = 0.5 * (double)TILE * a.step;
     const double xc = a.x0 + ((double)t0 + 0.5 * (double)TILE - 0.5) * a.step;
     // FARFIELD: the background H/(1+(a x)^p) + N0 is analytic on the tile with its singularities ~x_c away, so it joins the
     // tile polynomial: u(s) = (a x_c)^p (1+eps s)^p (binomial series), then the reciprocal series of 1+u.
-    const bool harvey_poly = FARFIELD && (fabs(h) <= EPS_MAX * fabs(xc)) && (xc > 0.0);
-    if (FAST && !harvey_poly) {
-        if (tid < nh) s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
+    const bool harvey_poly = FARFIELD && bg && (fabs(h) <= EPS_MAX * fabs(xc)) && (xc > 0.0);
+    __shared__ double s_lto[TAMCMC_MAX_HARVEY];  // DELTA: ln(1e-3*tau_k) of the base point
+    if (FAST && bg && !harvey_poly) {
+        if (tid < nh) {
+            s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
+            if (DELTA) s_lto[tid] = log(1e-3 * nzo[3 * tid + 1]);
+        }
     }
     if (FARFIELD) {
         if (tid < NC) s_coef[tid] = 0.0;
@@ -286,8 +305,11 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             double f[NH];
 #pragma unroll
             for (int k = 0; k < NH; k++) f[k] = 0.0;
-            if (hl >= 0 && hl < nh) {
-                const double Hh = nz[3 * hl], tau = nz[3 * hl + 1], pw = nz[3 * hl + 2];
+            const bool lane_new = (hl >= 0 && hl < nh), lane_old = DELTA && (hl >= 32 && hl < 32 + nh);
+            if (lane_new || lane_old) {
+                const double *nq = lane_new ? nz : nzo;
+                const int ht = lane_new ? hl : hl - 32;
+                const double Hh = lane_new ? nq[3 * ht] : -nq[3 * ht], tau = nq[3 * ht + 1], pw = nq[3 * ht + 2];
                 if (tau != 0.0) {
                     const double eps = h / xc;
                     double u[NH];
@@ -312,7 +334,10 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                     double v = f[k];
                     double tot = 0.0;
                     for (int t = 0; t < nh; t++) tot = tot + __shfl(v, t, 64);
-                    if (hl == 0) s_coef[k] = tot + (k == 0 ? nz[nn - 1] : 0.0);
+                    if (DELTA)
+                        for (int t = 0; t < nh; t++) tot = tot + __shfl(v, 32 + t, 64);
+                    const double wn = DELTA ? (nz[nn - 1] - nzo[nn - 1]) : nz[nn - 1];
+                    if (hl == 0) s_coef[k] = tot + (k == 0 ? wn : 0.0);
                 }
             }
         }
@@ -509,7 +534,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                 s[1] = s[1] + log(Mv);
             }
         } else {
-            if (!harvey_poly) {
+            if (bg && !harvey_poly) {
                 const double lx = a.logx[bi];
                 for (int hh = 0; hh < nh; hh++) {
                     const double tau = nz[3 * hh + 1];
@@ -517,10 +542,26 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                         const double t = exp(nz[3 * hh + 2] * (s_lt[hh] + lx));
                         Mv = fma(nz[3 * hh], rcp_nr2(t + 1.0), Mv);
                     }
+                    if (DELTA) {
+                        const double tauo = nzo[3 * hh + 1];
+                        if (tauo != 0.0) {
+                            const double t = exp(nzo[3 * hh + 2] * (s_lto[hh] + lx));
+                            Mv = fma(-nzo[3 * hh], rcp_nr2(t + 1.0), Mv);
+                        }
+                    }
                 }
-                Mv = Mv + white;
+                Mv = Mv + (DELTA ? (white - nzo[nn - 1]) : white);
             }
-            if (valid) {
+            if (DELTA) {
+                // Mv = dM.  y/(M0+dM) - y/M0 = -y dM /(M0 (M0+dM));  ln(M0+dM) - ln M0 = log1p(dM/M0)
+                if (valid) {
+                    const double M0 = a.model0[(size_t)a.d_row[b] * a.Nx + bin[k]];
+                    const double r0 = rcp_nr2(M0), rn = rcp_nr2(M0 + Mv);
+                    s[0] = fma(-a.y[bi] * Mv, r0 * rn, s[0]);
+                    const double dl = Mv * r0;
+                    s[1] = s[1] + ((fabs(dl) < 1e-4) ? dl * fma(dl, fma(dl, 1.0 / 3.0, -0.5), 1.0) : log1p(dl));
+                }
+            } else if (valid) {
                 s[0] = fma(a.y[bi], rcp_nr2(Mv), s[0]);
                 prod = prod * Mv;
             }
@@ -530,7 +571,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             if (valid) a.model[(size_t)b * a.Nx + bin[k]] = Mv;
         }
     }
-    if (FAST) {
+    if (FAST && !DELTA) {
         if (prod > 1e-280 && prod < 1e280) s[1] = log(prod);
         else {  // product out of range (or NaN): the plain sum of logs
 #pragma unroll
@@ -606,6 +647,29 @@ hipError_t launch_loglike(LoglikeArgs a, int mode, int wgs, int K, bool write_mo
     if (mode == M_FAST) ok = launch_geom<M_FAST>(a, wgs, K, write_model, (int)grid, st);
     else if (mode == M_FAST_DIRECT) ok = launch_geom<M_FAST_DIRECT>(a, wgs, K, write_model, (int)grid, st);
     else ok = launch_geom<M_STRICT>(a, wgs, K, write_model, (int)grid, st);
+    if (!ok) return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int MODE>
+bool launch_geom_delta(const LoglikeArgs &a, int wgs, int K, int grid, hipStream_t st) {
+    if (wgs == 256 && K == 4) hipLaunchKernelGGL((k_loglike<MODE, 256, 4, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (wgs == 64 && K == 8) hipLaunchKernelGGL((k_loglike<MODE, 64, 8, false, true>), dim3(grid), dim3(64), 0, st, a);
+    else return false;
+    return true;
+}
+
+bool delta_geometry(int wgs, int K) { return (wgs == 256 && K == 4) || (wgs == 64 && K == 8); }
+
+hipError_t launch_loglike_delta(LoglikeArgs a, int mode, int wgs, int K, hipStream_t st) {
+    if (a.B <= 0) return hipSuccess;
+    if (!delta_geometry(wgs, K) || mode == M_STRICT || !a.d_range || !a.d_flags || !a.d_noise_old || !a.d_row || !a.model0) return hipErrorInvalidValue;
+    const int tb = wgs * K;
+    a.ntiles = (a.Nx + tb - 1) / tb;
+    const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
+    const long long grid = (long long)ntiles_pad * a.B;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    const bool ok = (mode == M_FAST) ? launch_geom_delta<M_FAST>(a, wgs, K, (int)grid, st) : launch_geom_delta<M_FAST_DIRECT>(a, wgs, K, (int)grid, st);
     if (!ok) return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -246,3 +246,40 @@ def test_fd_gradient_posterior_device_batch(pkg, oracle, synth, ctxs):
     P[idx[k_inc]] = 90.0 - 0.25 * h[k_inc]
     _, _, g_edge = c.fd_gradient_posterior(star, P, h, [T], 1.0)
     assert np.all(np.isfinite(g_edge))
+
+
+def test_windowed_fd_matches_full_fd(pkg, oracle, synth, ctxs):
+    """Windowed finite differences (delta tables: only the multiplets a perturbation changes, on their windows, against the
+    stored base model row) against the brute-force batch (every perturbed model rebuilt on all bins) and the oracle."""
+    star = synth.make_c3_star(nx=40000, step=0.05)
+    o = star.plength[0] + star.plength[1] + star.plength[2:6].sum()
+    star.params[o + 13] = 15.0   # asymmetry on: exercises the asymmetric far field with negative heights
+    y = _spectrum(oracle, star)
+    idx = star.index_to_relax
+    h = 1e-6 * np.maximum(np.abs(star.params[idx]), 1e-2)
+    T = np.array([1.0, 1.3, 2.2])
+    rng = np.random.default_rng(5)
+    P = np.tile(star.params, (3, 1))
+    P[1:, idx] *= 1 + 0.003 * rng.standard_normal((2, idx.size))
+    for name in ("fast", "fast_direct"):
+        c = ctxs[name]
+        c.set_option(pkg.OPT_WORKGROUP, 64 if name == "fast" else 256)
+        c.set_option(pkg.OPT_BINS_PER_THREAD, 8 if name == "fast" else 4)
+        c.set_spectrum(star.x, y)
+        c.set_option(pkg.OPT_FD_WINDOWED, 0)
+        l0_f, pr_f, g_f = c.fd_gradient_posterior(star, P, h, T, 1.0)
+        c.set_option(pkg.OPT_FD_WINDOWED, 1)
+        l0_w, pr_w, g_w = c.fd_gradient_posterior(star, P, h, T, 1.0)
+        assert np.allclose(l0_w, l0_f, rtol=1e-12) and np.array_equal(pr_w, pr_f)
+        scale = np.max(np.abs(g_f), axis=1, keepdims=True)
+        # the brute-force difference of two ~Nx-term sums carries ~1e-15 Nx / h of cancellation noise; the windowed one does not
+        tol = 5e-15 * star.x.size / h[None, :] + 1e-6 * scale
+        assert np.all(np.abs(g_w - g_f) <= tol), name
+    # against the CPU oracle (chain 0, likelihood part only)
+    c = ctxs["fast"]
+    _, g_like = c.fd_gradient(star.model_id, star.params, star.plength, idx, h, [1.0], 1.0)
+    _, l0_o, g_o = oracle.fd_gradient(star.model_id, star.params, star.plength, idx, h, star.x, y, 1.0, 1.0)
+    assert np.all(np.abs(g_like[0] - g_o) <= 5e-15 * star.x.size / h + 1e-6 * np.max(np.abs(g_o)))
+    # windowed differences have no cancellation: halving the step changes the gradient only by the O(h) truncation term
+    _, g_half = c.fd_gradient(star.model_id, star.params, star.plength, idx, 0.5 * h, [1.0], 1.0)
+    assert np.all(np.abs(g_half[0] - g_like[0]) <= 2e-4 * np.max(np.abs(g_o)) + 1e-3 * np.abs(g_like[0]))
