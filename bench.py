@@ -90,19 +90,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # one rank per GPU; TAMCMC_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks
+    backend = os.environ.get("TAMCMC_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
     pkg = entry.load_package()
     from tamcmc_c_amd import synth
 
     lam = 1.3
     star = synth.make_c3_star(seed=20240229 + rank, nx=a.nx, step=2000.0 / a.nx)
     prec = pkg.PRECISION_FAST if a.precision == "fast" else pkg.PRECISION_STRICT
-    ctx = pkg.HipContext(local_rank, precision=prec, timing=True, bins_per_thread=a.bins_per_thread or None, workgroup=a.workgroup or None)
+    ctx = pkg.HipContext(device_index, precision=prec, timing=True, bins_per_thread=a.bins_per_thread or None, workgroup=a.workgroup or None)
     # synthetic spectrum y = M(theta_true) * Exp(1): the model row comes from the GPU path itself (STRICT arithmetic)
     ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_STRICT)
     ctx.set_spectrum(star.x, np.ones_like(star.x))

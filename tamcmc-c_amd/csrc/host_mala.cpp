@@ -244,7 +244,7 @@ int MALA::parallel_tempering(Model_def *model) {
 
 // Forward-difference gradient of the tempered log-posterior for the chains flagged in `which`:
 // likelihood part in ONE batched device call (C x (Nvars+1) evaluations), prior part on the host.
-int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const std::vector<char> &which) {
+int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const std::vector<char> &which, bool fill_state) {
     std::vector<int> live;
     for (long m = 0; m < Nchains; m++)
         if (which[(size_t)m]) live.push_back((int)m);
@@ -253,7 +253,7 @@ int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const st
     const std::vector<int> &idx = model->get_index_to_relax();
     std::vector<int32_t> idx32(idx.begin(), idx.end()), pl(model->get_plength().begin(), model->get_plength().end());
     const size_t C = live.size();
-    std::vector<double> P(C * (size_t)Np), T(C), L0(C), G(C * (size_t)Nvars), h((size_t)Nvars);
+    std::vector<double> P(C * (size_t)Np), T(C), L0(C), Pr0(C), G(C * (size_t)Nvars), h((size_t)Nvars);
     for (long k = 0; k < Nvars; k++) h[(size_t)k] = fd_step_rel * std::max(std::abs(mu(0, k)), 1e-3);
     for (size_t c = 0; c < C; c++) {
         std::memcpy(&P[c * (size_t)Np], model->params.row(live[c]), (size_t)Np * sizeof(double));
@@ -265,13 +265,23 @@ int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const st
     extra.resize(10, 0.0);
     int rc = tamcmc_hip_fd_gradient_posterior(model->get_ctx(), model->get_model_id(), model->get_prior_class(), (int)C, P.data(), Np,
                                               pl.data(), idx32.data(), (int)Nvars, h.data(), T.data(), model->get_likelihood_params(),
-                                              model->get_priors().a.data(), sw32.data(), extra.data(), L0.data(), nullptr, G.data());
+                                              model->get_priors().a.data(), sw32.data(), extra.data(), L0.data(), Pr0.data(), G.data());
     if (rc == TAMCMC_ERR_EMPTY_WINDOW || rc == TAMCMC_ERR_NAN_WINDOW) rc = TAMCMC_OK;
     for (size_t c = 0; c < C; c++) {
         const int m = live[c];
         for (long k = 0; k < Nvars; k++) {
             const double g = G[c * (size_t)Nvars + (size_t)k];
             grad_out(m, k) = std::isfinite(g) ? g : 0.0;
+        }
+        if (fill_state) {  // the batch's base evaluation IS generate_model(m): prior -> model -> tempered logL (model_def.cpp:466-482)
+            model->logPrior[(size_t)m] = Pr0[c];
+            if (Pr0[c] != -INFINITY && !std::isnan(Pr0[c])) {
+                model->logLikelihood[(size_t)m] = L0[c];
+                model->logPosterior[(size_t)m] = L0[c] + Pr0[c];
+            } else {
+                model->logLikelihood[(size_t)m] = model->init_logLikelihood[(size_t)m];
+                model->logPosterior[(size_t)m] = -INFINITY;
+            }
         }
     }
     return rc;
@@ -309,13 +319,14 @@ int MALA::step(Model_def *cur, Model_def *prop, Data *data, Config *) {
         prop->update_params_with_vars(m);
     }
     // [2] ONE batched evaluation (MALA.cpp:488 for all chains)
-    rc = prop->generate_models_batch(data, Tcoefs);
-    if (rc) return rc;
-    if (use_drift) {
-        std::vector<char> need((size_t)Nchains);
-        for (long m = 0; m < Nchains; m++)
-            need[(size_t)m] = std::isfinite(prop->logPosterior[(size_t)m]) && !std::isnan(prop->logLikelihood[(size_t)m]);
-        rc = compute_gradients(prop, data, grad_prop, need);
+    if (!use_drift) {
+        rc = prop->generate_models_batch(data, Tcoefs);
+        if (rc) return rc;
+    } else {
+        // Langevin: the finite-difference batch of every proposal -- its base evaluation is the proposal's own
+        // prior / model / logL, the other Nvars give the gradient the reverse-move density needs
+        std::vector<char> all((size_t)Nchains, 1);
+        rc = compute_gradients(prop, data, grad_prop, all, true);
         if (rc) return rc;
     }
     // [3] accept / reject (MALA.cpp:490-551)

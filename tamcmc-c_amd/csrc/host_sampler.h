@@ -167,7 +167,8 @@ class MALA {  // MALA.h:26-69
     void p3_fct(std::vector<double> &x);
     // one iteration of the loop body MALA.cpp:645-703 for ALL chains (propose all -> batched evaluate -> accept all)
     int step(Model_def *model_current, Model_def *model_propose, Data *data_struc, Config *cfg);
-    int compute_gradients(Model_def *model, Data *data_struc, Matrix &grad_out, const std::vector<char> &which);
+    int compute_gradients(Model_def *model, Data *data_struc, Matrix &grad_out, const std::vector<char> &which,
+                          bool fill_state = false);
     const Matrix &factor(int m);
     bool learn_at(long i) const;  // MALA.cpp:656-667: is the proposal law updated after iteration i?
     uint64_t get_seed() const { return seed; }

@@ -101,3 +101,27 @@ def test_posterior_recovers_truth(pkg, oracle, synth, ctx):
     assert np.all(std[fidx] < 3.0) and np.all(std[fidx] > 1e-4)
     mh, sh = res["host"]
     assert np.all(np.abs(mh[fidx] - mean[fidx]) < 4 * np.maximum(std[fidx], sh[fidx]))
+
+
+def test_langevin_drift_sampler(pkg, oracle, synth, ctx):
+    """use_drift=1 (the path the reference leaves as stubs, MALA.cpp:321-337,496-500): forward-difference gradient from the
+    device FD batches, preconditioned drift, asymmetric-proposal correction.  It must sample the same posterior as the
+    random-walk engine (means within Monte-Carlo error) and accept at a healthy rate."""
+    star = _star_with_data(pkg, oracle, synth, nx=4000, seed=5)
+    ctx.set_spectrum(star.x, star.y)
+    res = {}
+    for drift in (0, 1):
+        s = pkg.Sampler(ctx, star, engine="host", use_drift=drift, nchains=4, lambda_temp=1.6, seed=13, Nt_learn=(100, 1300),
+                        periods_learn=(1,), c0=5.0)
+        s.run(1300, record=False)
+        smp, stt = s.run(1500, stats=True)
+        cold = smp[:, 0, :]
+        acc = np.mean(np.any(cold[1:] != cold[:-1], axis=1))
+        assert np.all(np.isfinite(stt))
+        assert 0.05 < acc < 0.95, (drift, acc)
+        res[drift] = (cold.mean(0), cold.std(0))
+        s.close()
+    fidx = [i for i, k in enumerate(star.index_to_relax) if star.names[k] == "Frequency_l"]
+    m0, s0 = res[0]
+    m1, s1 = res[1]
+    assert np.all(np.abs(m0[fidx] - m1[fidx]) < 4 * np.maximum(s0[fidx], s1[fidx]))
