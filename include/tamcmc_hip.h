@@ -126,12 +126,13 @@ int tamcmc_hip_fd_gradient(tamcmc_hip_ctx *ctx, int model_id, int C, const doubl
  * its perturbed vector on the device (prior_class 2 = io_MS_Global, 3 = io_local; priors = 4 x Nparams row-major table,
  * priors_switch = primitive ids, extra_priors[10]: Input_Data of tamcmc/headers/data.h:51-62).  Where the forward point
  * leaves a prior's support the backward difference of the prior is used, else that prior term is flat.
- * Out: logL0[C] (tempered), logPr0[C] (may be NULL), grad[C x Nvars]. */
+ * Out: logL0[C] (tempered), logPr0[C] (may be NULL), grad[C x Nvars], grad_prior[C x Nvars] (may be NULL: the prior's
+ * share of grad, so that a caller can re-temper the likelihood share after a parallel-tempering swap). */
 int tamcmc_hip_fd_gradient_posterior(tamcmc_hip_ctx *ctx, int model_id, int prior_class, int C, const double *params,
                                      int64_t Nparams, const int32_t *plength, const int32_t *index_to_relax, int Nvars,
                                      const double *hstep, const double *Tcoefs, double p, const double *priors,
                                      const int32_t *priors_switch, const double *extra_priors, double *logL0, double *logPr0,
-                                     double *grad);
+                                     double *grad, double *grad_prior);
 
 /* Timing of the likelihood kernel measured with HIP events on the context's own stream
  * (enabled by TAMCMC_OPT_TIMING): totals since the last reset. */

@@ -52,7 +52,7 @@ ABI = [
     ("tamcmc_hip_loglike_params_batch", C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int64, _ip, _dp, C.c_double, _dp, _dp, _ip]),
     ("tamcmc_hip_fd_gradient", C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int64, _ip, _ip, C.c_int, _dp, _dp, C.c_double, _dp, _dp]),
     ("tamcmc_hip_fd_gradient_posterior", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, C.c_int64, _ip, _ip, C.c_int, _dp, _dp, C.c_double,
-                                                  _dp, _ip, _dp, _dp, _dp, _dp]),
+                                                  _dp, _ip, _dp, _dp, _dp, _dp, _dp]),
     ("tamcmc_hip_get_kernel_stats", C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("tamcmc_hip_reset_kernel_stats", C.c_int, [_vp]),
 ]
@@ -204,11 +204,12 @@ class HipContext:
         plength, idx, h = _i32(star.plength), _i32(star.index_to_relax), _f64(hstep)
         pri, sw, ex = _f64(star.priors), _i32(star.priors_switch), _f64(star.extra_priors)
         T = _f64(Tcoefs) if Tcoefs is not None else None
-        l0, pr0, g = np.zeros(Cn), np.zeros(Cn), np.zeros((Cn, idx.size))
+        l0, pr0, g, gp = np.zeros(Cn), np.zeros(Cn), np.zeros((Cn, idx.size)), np.zeros((Cn, idx.size))
         st = self._L.tamcmc_hip_fd_gradient_posterior(self._h, int(star.model_id), int(star.prior_class), Cn, _p(params), Np,
                                                      _p(plength, _ip), _p(idx, _ip), idx.size, _p(h), _p(T), float(p), _p(pri),
-                                                     _p(sw, _ip), _p(ex), _p(l0), _p(pr0), _p(g))
+                                                     _p(sw, _ip), _p(ex), _p(l0), _p(pr0), _p(g), _p(gp))
         self._chk(st, tolerate=(ERR_EMPTY_WINDOW, ERR_NAN_WINDOW))
+        self.last_grad_prior = gp
         return l0, pr0, g
 
     def kernel_stats(self):

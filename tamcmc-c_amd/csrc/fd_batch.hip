@@ -162,7 +162,7 @@ using namespace tamcmc;
 static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const double *params, int64_t Nparams,
                   const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep, const double *Tcoefs,
                   double p, const double *priors, const int32_t *priors_switch, const double *extra_priors, double *logL0,
-                  double *logPr0, double *grad) {
+                  double *logPr0, double *grad, double *grad_prior) {
     if (!c) return TAMCMC_ERR_BAD_ARG;
     if (c->Nx <= 0) return TAMCMC_ERR_NO_SPECTRUM;
     if (C < 0 || Nvars < 0 || !params || !plength || !index_to_relax || !hstep || !logL0 || !grad || Nparams < 1) return TAMCMC_ERR_BAD_ARG;
@@ -347,6 +347,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
                 if (std::isfinite(prp)) gp = (prp - pr0) / happ;
                 else gp = std::isfinite(prm) ? (pr0 - prm) / happ : 0.0;  // forward point outside the support: backward, else flat
                 g += gp;
+                if (grad_prior) grad_prior[(size_t)ch * Nv + k] = gp;
             }
             grad[(size_t)ch * Nv + k] = g;
         }
@@ -360,17 +361,17 @@ int tamcmc_hip_fd_gradient(tamcmc_hip_ctx *c, int model_id, int C, const double 
                            const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep,
                            const double *Tcoefs, double p, double *logL0, double *grad) {
     return fd_run(c, model_id, 0, C, params, Nparams, plength, index_to_relax, Nvars, hstep, Tcoefs, p, nullptr, nullptr, nullptr,
-                  logL0, nullptr, grad);
+                  logL0, nullptr, grad, nullptr);
 }
 
 int tamcmc_hip_fd_gradient_posterior(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const double *params,
                                      int64_t Nparams, const int32_t *plength, const int32_t *index_to_relax, int Nvars,
                                      const double *hstep, const double *Tcoefs, double p, const double *priors,
                                      const int32_t *priors_switch, const double *extra_priors, double *logL0, double *logPr0,
-                                     double *grad) {
+                                     double *grad, double *grad_prior) {
     if (prior_class != 2 && prior_class != 3) return TAMCMC_ERR_BAD_MODEL;
     return fd_run(c, model_id, prior_class, C, params, Nparams, plength, index_to_relax, Nvars, hstep, Tcoefs, p, priors,
-                  priors_switch, extra_priors, logL0, logPr0, grad);
+                  priors_switch, extra_priors, logL0, logPr0, grad, grad_prior);
 }
 
 }  // extern "C"

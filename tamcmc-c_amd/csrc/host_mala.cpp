@@ -69,6 +69,8 @@ MALA::MALA(Config *cfg) {
     Lchol_valid.assign((size_t)Nchains, 0);
     grad_cur = Matrix(Nchains, Nvars);
     grad_prop = Matrix(Nchains, Nvars);
+    gradP_cur = Matrix(Nchains, Nvars);
+    gradP_prop = Matrix(Nchains, Nvars);
     grad_valid.assign((size_t)Nchains, 0);
 }
 
@@ -230,9 +232,17 @@ int MALA::parallel_tempering(Model_def *model) {
         model->logPosterior[(size_t)ind_B] = (double)(logL_A_TB + prA);
         std::swap(model->moved[(size_t)ind_A], model->moved[(size_t)ind_B]);
         std::swap(model->Pmove[(size_t)ind_A], model->Pmove[(size_t)ind_B]);
-        if (use_drift) {  // the stored gradient follows the position; re-temper its likelihood part
-            for (long k = 0; k < Nvars; k++) std::swap(grad_cur(ind_A, k), grad_cur(ind_B, k));
-            grad_valid[(size_t)ind_A] = grad_valid[(size_t)ind_B] = 0;  // recomputed at the new temperature
+        if (use_drift) {  // the stored gradient follows the position: grad = (likelihood share) T_old/T_new + (prior share)
+            const double TA = Tcoefs[(size_t)ind_A], TB = Tcoefs[(size_t)ind_B];
+            for (long k = 0; k < Nvars; k++) {
+                const double gLA = grad_cur(ind_A, k) - gradP_cur(ind_A, k), gLB = grad_cur(ind_B, k) - gradP_cur(ind_B, k);
+                const double pA = gradP_cur(ind_A, k), pB = gradP_cur(ind_B, k);
+                gradP_cur(ind_A, k) = pB;
+                gradP_cur(ind_B, k) = pA;
+                grad_cur(ind_A, k) = gLB * TB / TA + pB;   // B's position now sits at temperature T_A
+                grad_cur(ind_B, k) = gLA * TA / TB + pA;
+            }
+            std::swap(grad_valid[(size_t)ind_A], grad_valid[(size_t)ind_B]);
         }
         model->swaped = true;
         model->Pswap = r_T;
@@ -253,7 +263,7 @@ int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const st
     const std::vector<int> &idx = model->get_index_to_relax();
     std::vector<int32_t> idx32(idx.begin(), idx.end()), pl(model->get_plength().begin(), model->get_plength().end());
     const size_t C = live.size();
-    std::vector<double> P(C * (size_t)Np), T(C), L0(C), Pr0(C), G(C * (size_t)Nvars), h((size_t)Nvars);
+    std::vector<double> P(C * (size_t)Np), T(C), L0(C), Pr0(C), G(C * (size_t)Nvars), GP(C * (size_t)Nvars), h((size_t)Nvars);
     for (long k = 0; k < Nvars; k++) h[(size_t)k] = fd_step_rel * std::max(std::abs(mu(0, k)), 1e-3);
     for (size_t c = 0; c < C; c++) {
         std::memcpy(&P[c * (size_t)Np], model->params.row(live[c]), (size_t)Np * sizeof(double));
@@ -265,13 +275,15 @@ int MALA::compute_gradients(Model_def *model, Data *, Matrix &grad_out, const st
     extra.resize(10, 0.0);
     int rc = tamcmc_hip_fd_gradient_posterior(model->get_ctx(), model->get_model_id(), model->get_prior_class(), (int)C, P.data(), Np,
                                               pl.data(), idx32.data(), (int)Nvars, h.data(), T.data(), model->get_likelihood_params(),
-                                              model->get_priors().a.data(), sw32.data(), extra.data(), L0.data(), Pr0.data(), G.data());
+                                              model->get_priors().a.data(), sw32.data(), extra.data(), L0.data(), Pr0.data(), G.data(), GP.data());
     if (rc == TAMCMC_ERR_EMPTY_WINDOW || rc == TAMCMC_ERR_NAN_WINDOW) rc = TAMCMC_OK;
     for (size_t c = 0; c < C; c++) {
         const int m = live[c];
         for (long k = 0; k < Nvars; k++) {
-            const double g = G[c * (size_t)Nvars + (size_t)k];
+            const double g = G[c * (size_t)Nvars + (size_t)k], gp = GP[c * (size_t)Nvars + (size_t)k];
             grad_out(m, k) = std::isfinite(g) ? g : 0.0;
+            Matrix &gpr = (&grad_out == &grad_cur) ? gradP_cur : gradP_prop;
+            gpr(m, k) = std::isfinite(g) ? gp : 0.0;  // prior share, kept apart: the likelihood share is re-tempered on a swap
         }
         if (fill_state) {  // the batch's base evaluation IS generate_model(m): prior -> model -> tempered logL (model_def.cpp:466-482)
             model->logPrior[(size_t)m] = Pr0[c];
@@ -361,7 +373,10 @@ int MALA::step(Model_def *cur, Model_def *prop, Data *data, Config *) {
             cur->logPrior[(size_t)m] = prop->logPrior[(size_t)m];
             cur->logPosterior[(size_t)m] = prop->logPosterior[(size_t)m];
             cur->moved[(size_t)m] = 1;
-            if (use_drift) std::memcpy(grad_cur.row(m), grad_prop.row(m), (size_t)Nvars * sizeof(double));
+            if (use_drift) {
+                std::memcpy(grad_cur.row(m), grad_prop.row(m), (size_t)Nvars * sizeof(double));
+                std::memcpy(gradP_cur.row(m), gradP_prop.row(m), (size_t)Nvars * sizeof(double));
+            }
         } else cur->moved[(size_t)m] = 0;
         cur->Pmove[(size_t)m] = (double)r;
         cur->comparator_MH[(size_t)m] = u;

@@ -143,6 +143,7 @@ class MALA {  // MALA.h:26-69
     std::vector<char> Lchol_valid;
     // Langevin state (use_drift): gradient of the tempered log-posterior at the current / proposed position
     Matrix grad_cur, grad_prop;
+    Matrix gradP_cur, gradP_prop;       // the prior's share of those gradients (not tempered)
     std::vector<char> grad_valid;
 
   public:
