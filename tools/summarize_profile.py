@@ -22,7 +22,7 @@ agg = collections.defaultdict(list)
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     for f in glob.glob(f"{src}/{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "k_loglike<1, 64, 8, false>" in r["Kernel_Name"]:
+            if "k_loglike<1, 64, 8, false" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 if agg:
     lines += ["## PMC, kernel `k_loglike<FAST, workgroup 64, K=8>` (default geometry), 20-evaluation launch (C3), mean over 10 launches, separate passes", "",
