@@ -287,3 +287,41 @@ def test_windowed_fd_matches_full_fd(pkg, oracle, synth, ctxs):
     #  crossing a bin between h and h/2 shows up as a jump; that is the model's property, build_lorentzian.cpp:645-649)
     okc = np.abs(g_half[0] - g_like[0]) <= 3e-3 * np.max(np.abs(g_o)) + 1e-2 * np.abs(g_like[0])
     assert okc.mean() >= 0.95
+
+
+def test_many_multiplets_multiple_chunks(pkg, oracle, synth, ctxs):
+    """More than 64 multiplets per evaluation (the kernel stages them in chunks of 64): 30 radial orders x l<=3 = 120
+    multiplets (BASELINE config C5 has O(100-300)); every mode and geometry family, plus the windowed gradient."""
+    rng = np.random.default_rng(21)
+    p, pl = synth.make_params_aj_model(rng, lmax=3, nfreqs=30, dnu=40.0, epsilon=0.3, d0l=-0.4, asym=8.0, n_first=8,
+                                       noise=np.array([2.0, 30.0, 2.0, 1.0, 3.0, 2.5, 0.05]), dl_shift=(0, 0, -1, -1))
+    o = pl[0] + pl[1] + pl[2:6].sum()
+    p[o] = 0.6          # a1
+    p[o + 14:o + 14 + 30] = rng.uniform(0.1, 0.4, 30)   # narrow widths
+    x = synth.grid(60000, 250.0, 0.025)   # 250..1750 muHz
+    st, m_o = oracle.call_model(23, p, pl, x)
+    assert st == 0
+    y = m_o * np.random.default_rng(3).exponential(1.0, x.size)
+    ref = oracle.chi22p_ld(y, m_o, 1)
+    for name, wg, K, tol_m in (("strict", 256, 2, 1e-15), ("strict", 64, 8, 1e-15), ("fast", 64, 8, 1e-12), ("fast", 256, 4, 1e-12),
+                               ("fast_direct", 256, 4, 1e-12)):
+        c = ctxs[name]
+        c.set_option(pkg.OPT_WORKGROUP, wg)
+        c.set_option(pkg.OPT_BINS_PER_THREAD, K)
+        c.set_spectrum(x, y)
+        logL, model, status = c.loglike_params_batch(23, p, pl, want_model=True)
+        assert status[0] == 0
+        assert np.max(np.abs(model[0] - m_o) / m_o) <= tol_m, (name, wg, K)
+        assert abs(logL[0] - ref) <= 1e-11 * abs(ref)
+    # windowed vs brute-force gradient over a handful of variables (heights, one frequency of each degree, a1, widths, noise)
+    idx = np.array([0, 7, o - 90, o - 60, o - 30, o - 1, o, o + 14, o + 20, o + 14 + 30 + 3, o + 14 + 30 + 6], dtype=np.int32)
+    h = 1e-6 * np.maximum(np.abs(p[idx]), 1e-2)
+    c = ctxs["fast"]
+    c.set_option(pkg.OPT_WORKGROUP, 64)
+    c.set_option(pkg.OPT_BINS_PER_THREAD, 8)
+    c.set_spectrum(x, y)
+    c.set_option(pkg.OPT_FD_WINDOWED, 0)
+    _, g_f = c.fd_gradient(23, p, pl, idx, h, [1.0], 1.0)
+    c.set_option(pkg.OPT_FD_WINDOWED, 1)
+    _, g_w = c.fd_gradient(23, p, pl, idx, h, [1.0], 1.0)
+    assert np.all(np.abs(g_w - g_f) <= 5e-14 * x.size / h + 1e-6 * np.max(np.abs(g_f)))

@@ -125,3 +125,17 @@ def test_langevin_drift_sampler(pkg, oracle, synth, ctx):
     m0, s0 = res[0]
     m1, s1 = res[1]
     assert np.all(np.abs(m0[fidx] - m1[fidx]) < 4 * np.maximum(s0[fidx], s1[fidx]))
+
+
+def test_forty_chains_device_engine(pkg, oracle, synth, ctx):
+    """BASELINE config 5 asks for 40 tempered chains; the reference caps Nchains at 24 (MALA.cpp:580-587), this build at 64."""
+    star = _star_with_data(pkg, oracle, synth, nx=2048, seed=2)
+    ctx.set_spectrum(star.x, star.y)
+    s = pkg.Sampler(ctx, star, engine="device", nchains=40, lambda_temp=1.15, seed=4, Nt_learn=(10**9, 10**9 + 1), periods_learn=(1,))
+    smp, stt = s.run(150, stats=True)
+    st = s.state()
+    assert smp.shape == (150, 40, star.nvars) and np.all(np.isfinite(stt))
+    assert st["swap_attempts"] == 149 and st["swaps"] > 10
+    moved = [(smp[1:, m] != smp[:-1, m]).any() for m in range(40)]
+    assert all(moved)
+    s.close()
