@@ -179,7 +179,7 @@ __device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const doub
 //   (1) proposes iteration `it` from that state: x' = x + L z, log-prior, params' -> multiplet table.
 template <bool PROPOSE>
 __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const long it, const int P, const int pending,
-                                               const long rec, const int learn_pending, double *scratch) {
+                                               const long rec, const int learn_pending, double *scratch, const int c_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int Np = a.desc.Np, Nv = a.Nv, C = a.C;
     double *s_params = (double *)s_raw;          // [Np]   current, then proposed parameter vector
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
     __shared__ AcceptOut s_own, s_partner;
     __shared__ double s_scal[2];
 
-    const int m = blockIdx.x, tid = threadIdx.x;
+    const int m = blockIdx.x + c_off, tid = threadIdx.x;  // c_off: first chain of this launch's chain group
     const int Q = P ^ 1;
 #define STAMP(k) do { if (PROPOSE && a.dbg && m == 0 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
     STAMP(0);
@@ -332,6 +332,12 @@ struct DevSampler::Impl {
     size_t smp_cap = 0, stat_cap = 0;
     size_t lds_base = 0, lds_adapt = 0;
     int parity = 0;  // which of the two state buffers holds the chains' current state
+    // chain groups: the chains are split into G contiguous groups, each on its own stream, so that one group's k_iterate
+    // overlaps the other groups' k_loglike (an iteration is a serial k_iterate -> k_loglike chain per group)
+    int G = 1;
+    hipStream_t gst[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_kb[4], ev_ki[4], ev_fork, ev_join[4];
+    bool ev_made = false;
 
     template <typename T>
     hipError_t dalloc(T **p, size_t n) {
@@ -351,6 +357,11 @@ DevSampler::~DevSampler() {
     }
     for (void *p : impl->allocs) (void)hipFree(p);
     for (int i = 0; i < impl->n_ev; i++) { (void)hipEventDestroy(impl->ev[i][0]); (void)hipEventDestroy(impl->ev[i][1]); }
+    if (impl->ev_made) {
+        (void)hipEventDestroy(impl->ev_fork);
+        for (int g = 0; g < 4; g++) { (void)hipEventDestroy(impl->ev_kb[g]); (void)hipEventDestroy(impl->ev_ki[g]); (void)hipEventDestroy(impl->ev_join[g]); }
+        for (int g = 1; g < 4; g++) if (impl->gst[g]) (void)hipStreamDestroy(impl->gst[g]);
+    }
     delete impl;
 }
 
@@ -425,6 +436,23 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(hipGetLastError());
     a.desc.poly = d_tab;
     for (int i = 0; i < 64; i++) { DCHK(hipEventCreate(&I.ev[i][0])); DCHK(hipEventCreate(&I.ev[i][1])); I.n_ev = i + 1; }
+    {
+        const char *eg = getenv("TAMCMC_CHAIN_GROUPS");
+        int G = eg ? atoi(eg) : (in.C >= 8 ? 2 : 1);
+        if (G < 1) G = 1;
+        if (G > 4) G = 4;
+        if (G > in.C) G = in.C;
+        I.G = G;
+        I.gst[0] = st;
+        for (int g = 1; g < G; g++) DCHK(hipStreamCreateWithFlags(&I.gst[g], hipStreamNonBlocking));
+        DCHK(hipEventCreateWithFlags(&I.ev_fork, hipEventDisableTiming));
+        for (int g = 0; g < 4; g++) {
+            DCHK(hipEventCreateWithFlags(&I.ev_kb[g], hipEventDisableTiming));
+            DCHK(hipEventCreateWithFlags(&I.ev_ki[g], hipEventDisableTiming));
+            DCHK(hipEventCreateWithFlags(&I.ev_join[g], hipEventDisableTiming));
+        }
+        I.ev_made = true;
+    }
     DCHK(hipStreamSynchronize(st));
     return TAMCMC_OK;
 }
@@ -523,12 +551,24 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     DevSamplerArgs args = a;
     if (!samples) args.samples = nullptr;
     if (!stats) args.stats = nullptr;
-    LoglikeArgs la;
-    la.x = c->dx.p; la.y = c->dy.p; la.logx = c->dlogx.p; la.Nx = a.desc.Nx; la.B = a.C; la.ntiles = a.ntiles;
-    la.x0 = a.desc.x_first; la.step = a.desc.step;
-    la.mults = a.mults; la.offsets = a.pairs; la.noise = a.noise; la.noise_stride = a.desc.stride;
-    la.nharvey = a.nh; la.nnoise = a.nn; la.partials = a.partials; la.model = nullptr;
-    la.dbg = a.dbg ? a.dbg + 8 : nullptr;
+    // chain groups [goff[g], goff[g+1])
+    const int G = I.G;
+    int goff[5];
+    for (int g = 0; g <= G; g++) goff[g] = (int)(((long)a.C * g) / G);
+    auto group_of = [&](int chain) { int g = 0; while (g + 1 < G && chain >= goff[g + 1]) g++; return g; };
+    LoglikeArgs la[4];
+    for (int g = 0; g < G; g++) {
+        LoglikeArgs &l = la[g];
+        const int co = goff[g];
+        l.x = c->dx.p; l.y = c->dy.p; l.logx = c->dlogx.p; l.Nx = a.desc.Nx; l.B = goff[g + 1] - co; l.ntiles = a.ntiles;
+        l.x0 = a.desc.x_first; l.step = a.desc.step;
+        l.mults = a.mults; l.offsets = a.pairs + 2 * co; l.noise = a.noise + (size_t)co * a.desc.stride; l.noise_stride = a.desc.stride;
+        l.nharvey = a.nh + co; l.nnoise = a.nn + co; l.partials = a.partials + (size_t)co * a.ntiles * 2; l.model = nullptr;
+        l.dbg = (a.dbg && g == 0) ? a.dbg + 8 : nullptr;
+    }
+    // the extra streams start after everything already enqueued on the context stream
+    DCHK(hipEventRecord(I.ev_fork, st));
+    for (int g = 1; g < G; g++) DCHK(hipStreamWaitEvent(I.gst[g], I.ev_fork, 0));
     int used_ev = 0;
     const long ev_every = n_iter > 64 ? n_iter / 64 : 1;
     int P = I.parity, pending = 0;
@@ -537,18 +577,52 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         const int learn_p = (pending && learn && learn[i - 1]) ? 1 : 0;
         const size_t lds = I.lds_base + ((learn_p && a.chol_in_lds) ? I.lds_adapt : 0);
         const long rec = (pending && (samples || stats)) ? i - 1 : (long)-1;
-        if (i < n_iter) {
-            hipLaunchKernelGGL(k_iterate<true>, dim3(a.C), dim3(TB), lds, st, args, it, P, pending, rec, learn_p, I.adapt_scratch);
-            P ^= 1;
-            pending = 1;
-            const bool timed = c->timing && (i % ev_every == 0) && used_ev < I.n_ev;
-            if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
-            DCHK(launch_loglike(la, c->precision, c->wgs, c->K, false, st));
-            if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
-        } else {  // settle the last iteration of this run (MH test, swap, record, adaptation); nothing is proposed
-            hipLaunchKernelGGL(k_iterate<false>, dim3(a.C), dim3(TB), lds, st, args, it, P, pending, rec, learn_p, I.adapt_scratch);
-            P ^= 1;
+        // does settling iteration it-1 swap a pair that straddles two groups? (same draw as the kernel: Philox is host/device)
+        int gA = -1, gB = -1;
+        if (pending && G > 1) {
+            const long itp = it - 1;
+            if (a.dN_mixing > 0 && (itp % a.dN_mixing == 0) && itp != 0 && a.C > 1) {
+                double u, u2;
+                rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)itp, 0, u, u2);
+                int A = (int)(u2 * (double)(a.C - 1));
+                if (A > a.C - 2) A = a.C - 2;
+                if (group_of(A) != group_of(A + 1)) { gA = group_of(A); gB = group_of(A + 1); }
+            }
         }
+        if (gA >= 0) {  // each of the two groups needs the other's k_loglike(it-1) before it settles the pair
+            DCHK(hipEventRecord(I.ev_kb[gA], I.gst[gA]));
+            DCHK(hipEventRecord(I.ev_kb[gB], I.gst[gB]));
+            DCHK(hipStreamWaitEvent(I.gst[gA], I.ev_kb[gB], 0));
+            DCHK(hipStreamWaitEvent(I.gst[gB], I.ev_kb[gA], 0));
+        }
+        for (int g = 0; g < G; g++) {
+            const int cnt = goff[g + 1] - goff[g];
+            if (i < n_iter)
+                hipLaunchKernelGGL(k_iterate<true>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
+            else  // settle the last iteration of this run (MH test, swap, record, adaptation); nothing is proposed
+                hipLaunchKernelGGL(k_iterate<false>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
+        }
+        if (gA >= 0) {  // ... and must not overwrite (next iteration) what the other group's settle is still reading
+            DCHK(hipEventRecord(I.ev_ki[gA], I.gst[gA]));
+            DCHK(hipEventRecord(I.ev_ki[gB], I.gst[gB]));
+            DCHK(hipStreamWaitEvent(I.gst[gA], I.ev_ki[gB], 0));
+            DCHK(hipStreamWaitEvent(I.gst[gB], I.ev_ki[gA], 0));
+        }
+        P ^= 1;
+        pending = 1;
+        if (i < n_iter) {
+            for (int g = 0; g < G; g++) {
+                const bool timed = g == 0 && c->timing && (i % ev_every == 0) && used_ev < I.n_ev;
+                if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], I.gst[g]));
+                DCHK(launch_loglike(la[g], c->precision, c->wgs, c->K, false, I.gst[g]));
+                if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], I.gst[g])); used_ev++; }
+            }
+        }
+    }
+    // join: the context stream continues after every group
+    for (int g = 1; g < G; g++) {
+        DCHK(hipEventRecord(I.ev_join[g], I.gst[g]));
+        DCHK(hipStreamWaitEvent(st, I.ev_join[g], 0));
     }
     I.parity = P;
     if (a.dbg) {  // phase stamps of the last k_iterate<true> launch (100 MHz wall clock), workgroup 0
@@ -573,8 +647,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             tot += ms;
         }
         // extrapolate the sampled launches to all launches of this run (every launch has the same shape)
-        c->kernel_ms += tot / used_ev * (double)n_iter;
-        c->launches += n_iter;
+        // (with chain groups every launch carries C/G evaluations and overlaps the other groups' kernels)
+        c->kernel_ms += tot / used_ev * (double)n_iter * I.G;
+        c->launches += n_iter * I.G;
         c->evals += n_iter * a.C;
     }
     return TAMCMC_OK;
