@@ -126,6 +126,11 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     a.nnoise = (const int32_t *)(c->d_stage.p + L.off_nn);
     a.partials = c->d_part.p;
     a.model = model ? c->d_model.p : nullptr;
+    {
+        const int32_t *pairs = (const int32_t *)(c->h_stage.p + L.off_pairs);
+        const tamcmc_multiplet *hm = (const tamcmc_multiplet *)(c->h_stage.p + L.off_mults);
+        a.tile_rot = tamcmc::pick_tile_rot(hm + pairs[0], pairs[1] - pairs[0], a.x0, a.step, tb, ntiles);
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
     HIPCHK(c, tamcmc::launch_loglike(a, c->precision, c->wgs, c->K, model != nullptr, st));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));

@@ -29,6 +29,7 @@
 #include "dev_sampler.h"
 #include "kernels.h"
 #include "dev_unpack.h"
+#include "mode_tables.h"
 #include "rng.h"
 
 namespace tamcmc {
@@ -334,6 +335,8 @@ struct DevSampler::Impl {
     int parity = 0;  // which of the two state buffers holds the chains' current state
     // chain groups: the chains are split into G contiguous groups, each on its own stream, so that one group's k_iterate
     // overlaps the other groups' k_loglike (an iteration is a serial k_iterate -> k_loglike chain per group)
+    int tile_rot = 0;  // launch-order hint of k_loglike (first near-field tile of chain 0's initial table)
+    std::vector<int32_t> h_plength;
     int G = 1;
     hipStream_t gst[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_kb[4], ev_ki[4], ev_fork, ev_join[4];
@@ -388,6 +391,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DevSamplerArgs &a = I.a;
     a.desc.model_id = in.model_id; a.desc.prior_class = in.prior_class; a.C = in.C; a.desc.Np = in.Np; a.Nv = in.Nv;
     a.desc.per = mt::count_multiplets(in.model_id, in.plength);
+    I.h_plength.assign(in.plength, in.plength + 11);
     if (a.desc.per < 0) return TAMCMC_ERR_BAD_MODEL;
     a.desc.stride = in.plength[8] > 0 ? in.plength[8] : 1;
     if ((a.desc.stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
@@ -470,6 +474,15 @@ int DevSampler::upload_state(const double *vars, const double *params, const dou
     DCHK(up(a.logL_cur + P * C, logL, C, st)); DCHK(up(a.logPr_cur + P * C, logPr, C, st)); DCHK(up(a.logPost_cur + P * C, logPost, C, st));
     DCHK(up(a.init_logL, init_logL, C, st));
     DCHK(hipStreamSynchronize(st));
+    {  // launch-order hint from chain 0's table at the uploaded position
+        std::vector<tamcmc_multiplet> tab((size_t)a.desc.per > 0 ? (size_t)a.desc.per : 1);
+        std::vector<double> nz((size_t)a.desc.stride);
+        int n = 0, nh = 0, nn = 0;
+        const int tb = tile_bins(c->wgs, c->K);
+        I.tile_rot = 0;
+        if (build_mode_table(a.desc.model_id, params, I.h_plength.data(), c->hx.data(), c->Nx, tab.data(), a.desc.per, &n, nz.data(), &nh, &nn) == TAMCMC_OK && n <= a.desc.per)
+            I.tile_rot = pick_tile_rot(tab.data(), n, a.desc.x_first, a.desc.step, tb, (int)((c->Nx + tb - 1) / tb));
+    }
     return TAMCMC_OK;
 }
 
@@ -565,6 +578,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         l.mults = a.mults; l.offsets = a.pairs + 2 * co; l.noise = a.noise + (size_t)co * a.desc.stride; l.noise_stride = a.desc.stride;
         l.nharvey = a.nh + co; l.nnoise = a.nn + co; l.partials = a.partials + (size_t)co * a.ntiles * 2; l.model = nullptr;
         l.dbg = (a.dbg && g == 0) ? a.dbg + 8 : nullptr;
+        l.tile_rot = I.tile_rot;
     }
     // the extra streams start after everything already enqueued on the context stream
     DCHK(hipEventRecord(I.ev_fork, st));

@@ -17,6 +17,7 @@ struct LoglikeArgs {
     double x0, step;      // regular grid: x[i] = x0 + i*step (far-field tile geometry)
     int B;                // evaluations in this launch
     int ntiles;           // filled by launch_loglike
+    int tile_rot = 0;     // tile dispatched first (launch order wraps around); any value in [0, ntiles) gives the same results
     const tamcmc_multiplet *mults;  // concatenated multiplet tables
     const int32_t *offsets;         // [2B] (begin,end) multiplet range per evaluation
     const double *noise;            // [B x noise_stride] |noise params|
@@ -35,6 +36,19 @@ struct LoglikeArgs {
     const int32_t *d_row = nullptr;       // [B]  row of model0 holding the base model of evaluation b
     const double *model0 = nullptr;       // [rows x Nx] base model rows
 };
+
+// Tile to dispatch first: three tiles below the lowest multiplet centre of a representative table (so the near-field tiles lead
+// the launch).  A hint only -- results do not depend on it.
+inline int pick_tile_rot(const tamcmc_multiplet *m, int n, double x0, double step, int tile, int ntiles) {
+    double fmin = 0.0;
+    bool any = false;
+    for (int i = 0; i < n; i++)
+        if (m[i].fc == m[i].fc && (!any || m[i].fc < fmin)) { fmin = m[i].fc; any = true; }
+    if (!any || !(step > 0.0) || ntiles < 1) return 0;
+    const double t = (fmin - x0) / step / (double)tile - 3.0;
+    if (!(t > 0.0)) return 0;
+    return t >= (double)ntiles ? ntiles - 1 : (int)t;
+}
 
 int tile_bins(int wgs, int K);       // bins per workgroup = workgroup size x bins per thread
 bool valid_geometry(int wgs, int K);  // (256; 1,2,4) or (64; 4,8,16)

@@ -244,8 +244,12 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     const int xcd = id & 7;
     const int j = id >> 3;
     const int b = j % a.B;
-    const int tile = (j / a.B) * 8 + xcd;
+    // launch order = tile_rot, tile_rot+1, ..., wrapping: the caller points tile_rot at the first tile of the mode region so
+    // that the long-running tiles (near field) are dispatched first and the cheap far-field-only tiles fill the tail
+    int tile = (j / a.B) * 8 + xcd;
     if (tile >= a.ntiles) return;  // whole workgroup leaves before any barrier
+    tile += a.tile_rot;
+    if (tile >= a.ntiles) tile -= a.ntiles;
 
     const int tid = threadIdx.x;
 #define KSTAMP(k) do { if (a.dbg && b == 0 && tile == a.ntiles / 2 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
@@ -265,7 +269,9 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         }
     }
 
-    double xv[K], acc[K];
+    const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
+    tamcmc_multiplet g;
+    double xv[K], yv[K], acc[K];
     int bin[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -343,27 +349,23 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         }
     }
 
-    const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
+    // the power values are only needed in the epilogue: issued here, their latency hides behind the multiplet loop
     KSTAMP(1);
     for (int c0 = mbeg; c0 < mend; c0 += CHUNK) {
         __syncthreads();  // previous chunk fully consumed
         if (tid < 64) {
             const int idx = c0 + tid;
-            bool ov = false;
-            int i0 = 0, i1 = 0;
-            if (idx < mend) {
-                i0 = a.mults[idx].i0;
-                i1 = a.mults[idx].i1;
-                ov = (i0 < t1) && (i1 > t0);
-            }
+            g = a.mults[min(idx, mend - 1)];  // the whole row in ONE round trip (clamped index: lanes past the end stage nothing)
+            const int i0 = g.i0, i1 = g.i1;
+            const bool ov = (idx < mend) && (i0 < t1) && (i1 > t0);
             const unsigned long long mask = __ballot(ov);
             bool far = false;
             if (ov) {
                 // every overlapping multiplet is staged (in order) with its per-multiplet scalars hoisted; far ones are flagged
                 const int pos = __popcll(mask & ((1ull << tid) - 1ull));
-                const tamcmc_multiplet &g = a.mults[idx];
                 LdsMult &d = s_m[pos];
                 const int l = g.l;
+                const int nm = 2 * l + 1;
                 int flags = 0;
                 const bool full = (i0 <= t0 && i1 >= t1);
                 if (full) flags |= F_FULL;
@@ -379,19 +381,21 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                         const double beta2 = (ig * h) * (ig * h);
                         const double r2 = (g.asym != 0.0) ? RHO_MAX2_ASYM : RHO_MAX2;
                         far = true;
-                        for (int m = 0; m < 2 * l + 1; m++) {
+#pragma unroll
+                        for (int m = 0; m < 7; m++) {  // constant trip count: g stays in registers
                             const double A = ig * (g.nu[m] - xc);
-                            if (!(beta2 <= r2 * fma(A, A, 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
+                            if (m < nm && !(beta2 <= r2 * fma(A, A, 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
                         }
                     }
                     if (far) flags |= F_FAR;
                     else {
                         // prod_m (1 + ((x-nu_m) ig)^2) < (1e38)^7 = 1e266 on the whole tile?
-                        const double xlo = a.x[t0], xhi = a.x[t1 - 1];
+                        const double xlo = xc - h, xhi = xc + h;  // the nominal tile on the regular grid (a coarse bound)
                         bool safe = true;
-                        for (int m = 0; m < 2 * l + 1; m++) {
+#pragma unroll
+                        for (int m = 0; m < 7; m++) {
                             const double dm = fmax(fabs(xlo - g.nu[m]), fabs(xhi - g.nu[m])) * ig;
-                            if (!(fma(dm, dm, 1.0) < 1e38)) safe = false;  // also false for NaN/inf inputs
+                            if (m < nm && !(fma(dm, dm, 1.0) < 1e38)) safe = false;  // also false for NaN/inf inputs
                         }
                         if (safe) flags |= F_SAFE;
                     }
@@ -493,6 +497,9 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         }
     }
     KSTAMP(4);
+    // the power values: issued before the polynomial evaluation, consumed after it
+#pragma unroll
+    for (int k = 0; k < K; k++) yv[k] = a.y[min(bin[k], a.Nx - 1)];
     if (FAST) __syncthreads();  // s_lt / s_coef visible (also when the evaluation has no multiplet chunk)
     if (FARFIELD) {
         if (s_anyfar) {  // workgroup-uniform: far multiplets and/or the background series
@@ -530,7 +537,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             }
             Mv = Mv + white;
             if (valid) {
-                s[0] = s[0] + a.y[bi] * (1.0 / Mv);
+                s[0] = s[0] + yv[k] * (1.0 / Mv);
                 s[1] = s[1] + log(Mv);
             }
         } else {
@@ -557,12 +564,12 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                 if (valid) {
                     const double M0 = a.model0[(size_t)a.d_row[b] * a.Nx + bin[k]];
                     const double r0 = rcp_nr2(M0), rn = rcp_nr2(M0 + Mv);
-                    s[0] = fma(-a.y[bi] * Mv, r0 * rn, s[0]);
+                    s[0] = fma(-yv[k] * Mv, r0 * rn, s[0]);
                     const double dl = Mv * r0;
                     s[1] = s[1] + ((fabs(dl) < 1e-4) ? dl * fma(dl, fma(dl, 1.0 / 3.0, -0.5), 1.0) : log1p(dl));
                 }
             } else if (valid) {
-                s[0] = fma(a.y[bi], rcp_nr2(Mv), s[0]);
+                s[0] = fma(yv[k], rcp_nr2(Mv), s[0]);
                 prod = prod * Mv;
             }
         }
@@ -643,6 +650,7 @@ hipError_t launch_loglike(LoglikeArgs a, int mode, int wgs, int K, bool write_mo
     const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
     const long long grid = (long long)ntiles_pad * a.B;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.tile_rot < 0 || a.tile_rot >= a.ntiles) a.tile_rot = 0;
     bool ok;
     if (mode == M_FAST) ok = launch_geom<M_FAST>(a, wgs, K, write_model, (int)grid, st);
     else if (mode == M_FAST_DIRECT) ok = launch_geom<M_FAST_DIRECT>(a, wgs, K, write_model, (int)grid, st);
@@ -669,6 +677,7 @@ hipError_t launch_loglike_delta(LoglikeArgs a, int mode, int wgs, int K, hipStre
     const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
     const long long grid = (long long)ntiles_pad * a.B;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.tile_rot < 0 || a.tile_rot >= a.ntiles) a.tile_rot = 0;
     const bool ok = (mode == M_FAST) ? launch_geom_delta<M_FAST>(a, wgs, K, (int)grid, st) : launch_geom_delta<M_FAST_DIRECT>(a, wgs, K, (int)grid, st);
     if (!ok) return hipErrorInvalidValue;
     return hipGetLastError();
