@@ -38,6 +38,11 @@ struct DevSamplerArgs {
     double *partials;
     // records
     double *samples, *stats;
+    // speculative rounds (k_spec): D candidate slots per chain; per-chain progress, parity-doubled like the chain state
+    int D;
+    long *sp_done;   // [2][C] iterations whose MH test is done
+    int *sp_nprop;   // [2][C] candidates proposed by the last round
+    int *sp_phase;   // [2][C] 1 = waits for its partner to resolve the swap of iteration sp_done-1
 };
 #endif
 

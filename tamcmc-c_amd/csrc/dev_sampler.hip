@@ -173,6 +173,50 @@ __device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const doub
     __syncthreads();
 }
 
+// Proposal of iteration `it` for `chain` from the state in LDS (s_vars/s_params): x' = x + L z (MALA.cpp:348-355), L =
+// chol((Sigma+eps2) sigma) stored transposed, same Philox streams as the host engine; log-prior; params' -> multiplet table
+// written into slot `slot` of the likelihood kernel's input block.  Ends without a barrier.
+__device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int chain, long it, int slot, double *pv, double *pp,
+                               double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, long *dbg) {
+    const int Np = a.desc.Np, Nv = a.Nv, tid = threadIdx.x;
+#define PSTAMP(k) do { if (dbg && tid == 0) dbg[k] = (long)wall_clock64(); } while (0)
+    for (int k2 = tid; 2 * k2 < Nv; k2 += TB) {
+        double z0, z1;
+        rng_normal2(a.seed, RNG_PROPOSAL, (uint32_t)chain, (uint64_t)it, (uint32_t)k2, z0, z1);
+        s_z[2 * k2] = z0;
+        s_z[2 * k2 + 1] = z1;
+    }
+    unpack_begin(a.desc, U);
+
+    const double *LT = a.LT + (size_t)chain * Nv * Nv;
+    for (int i = tid; i < Nv; i += TB) {  // lane i owns row i: reads s_vars[i] only, every s_z[k]
+        double s = 0;
+        for (int k = 0; k <= i; k++) s = s + LT[(size_t)k * Nv + i] * s_z[k];
+        const double v = s_vars[i] + 0.0 + s;
+        s_vars[i] = v;
+        pv[i] = v;
+    }
+    __syncthreads();
+    PSTAMP(2);
+    for (int k = tid; k < Nv; k += TB) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
+    __syncthreads();
+    for (int i = tid; i < Np; i += TB) pp[i] = s_params[i];
+
+    // ---- log-prior, then params' -> multiplet table written into the likelihood kernel's input block ----
+    const double logPr = wg_log_prior(a.desc, s_params, U, true);
+    PSTAMP(4);
+    const bool live = (logPr != -INFINITY) && !isnan(logPr);  // model_def.cpp:472,476-480
+    TablePtrs T;
+    T.mults = a.mults; T.pairs = a.pairs; T.nh = a.nh; T.nn = a.nn; T.noise = a.noise;
+    wg_unpack(a.desc, s_params, U, slot, T, live);
+    if (tid == 0) {
+        *logPr_out = logPr;
+        *status_out = *U.status;
+    }
+    PSTAMP(6);
+#undef PSTAMP
+}
+
 // ONE kernel per MCMC iteration besides the likelihood kernel.  Workgroup m:
 //   (0) settles the pending iteration it-1 for chain m: MH test (own chain; the swap partner's too when chain m is in the
 //       swap pair), adjacent-pair parallel-tempering swap, writes the chain's new current state into the OTHER parity
@@ -279,43 +323,261 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
     __syncthreads();
 
     // ------------------------------------------------------------------ (1) propose iteration `it`
-    // x' = x + L z (MALA.cpp:348-355), L = chol((Sigma+eps2) sigma) stored transposed; same Philox streams as the host engine
-    for (int k2 = tid; 2 * k2 < Nv; k2 += TB) {
-        double z0, z1;
-        rng_normal2(a.seed, RNG_PROPOSAL, (uint32_t)m, (uint64_t)it, (uint32_t)k2, z0, z1);
-        s_z[2 * k2] = z0;
-        s_z[2 * k2 + 1] = z1;
-    }
-    unpack_begin(a.desc, U);
-
-    const double *LT = a.LT + (size_t)m * Nv * Nv;
-    double *pv = a.vars_prop + (size_t)Q * C * Nv + (size_t)m * Nv;
-    for (int i = tid; i < Nv; i += TB) {  // lane i owns row i: reads s_vars[i] only, every s_z[k]
-        double s = 0;
-        for (int k = 0; k <= i; k++) s = s + LT[(size_t)k * Nv + i] * s_z[k];
-        const double v = s_vars[i] + 0.0 + s;
-        s_vars[i] = v;
-        pv[i] = v;
-    }
-    __syncthreads();
-    STAMP(2);
-    for (int k = tid; k < Nv; k += TB) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
-    __syncthreads();
-    for (int i = tid; i < Np; i += TB) a.params_prop[(size_t)Q * C * Np + (size_t)m * Np + i] = s_params[i];
-
-    // ---- log-prior, then params' -> multiplet table written into the likelihood kernel's input block ----
-    const double logPr = wg_log_prior(a.desc, s_params, U, true);
-    STAMP(4);
-    const bool live = (logPr != -INFINITY) && !isnan(logPr);  // model_def.cpp:472,476-480
-    TablePtrs T;
-    T.mults = a.mults; T.pairs = a.pairs; T.nh = a.nh; T.nn = a.nn; T.noise = a.noise;
-    wg_unpack(a.desc, s_params, U, m, T, live);
-    if (tid == 0) {
-        a.logPr_prop[Q * C + m] = logPr;
-        a.status_prop[Q * C + m] = *U.status;
-    }
-    STAMP(6);
+    propose_common(a, U, m, it, m, a.vars_prop + (size_t)Q * C * Nv + (size_t)m * Nv, a.params_prop + (size_t)Q * C * Np + (size_t)m * Np,
+                   a.logPr_prop + Q * C + m, a.status_prop + Q * C + m, s_vars, s_params, s_z, (a.dbg && m == 0) ? a.dbg : nullptr);
 #undef STAMP
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Speculative rounds for stretches WITHOUT adaptation (the proposal law is frozen, e.g. the Acquire phase).
+// A Metropolis-Hastings chain rejects ~3 proposals out of 4; when iteration i is rejected, the proposal of i+1 is
+// x + L z_{i+1} from the SAME x.  A round therefore evaluates, per chain, the candidates of iterations d, d+1, .., d+D-1
+// all built on the chain's current x; the next round tests them in order and consumes iterations up to and including the
+// first acceptance (later candidates are discarded).  Every random number is addressed by (chain, iteration), so each
+// chain follows exactly the trajectory of the one-iteration-per-round engine -- the chains merely stop advancing in
+// lockstep.  Parallel-tempering swaps (iteration s, pair A_s) are the only coupling: a chain of the pair proposes no
+// candidate beyond s, and after its MH test of s it waits (phase 1) until its partner has also tested s; both
+// workgroups then resolve the swap from the same inputs.
+struct SpecOut {
+    long done;                     // iterations whose MH test is done, after this round's tests
+    int phase;                     // 1 = waiting for the partner at the swap of iteration done-1
+    int src_chain, src_cand;       // where the chain's state vector lives (parity P): cand -1 = src_chain's current vector
+    int n_rec, acc_last, swap_last;  // iterations consumed by this round's tests; was the last one accepted; is it a swap step of this chain
+    int resolved, swapped;
+    int nprop_new;
+    double r_last;
+    double logL0, logPr0, logPost0;  // before this round's tests
+    double logL, logPr, logPost;     // after the tests (and after the swap once resolved)
+};
+
+__device__ __forceinline__ bool is_swap_iter(const DevSamplerArgs &a, long i) {
+    return a.dN_mixing > 0 && (i % a.dN_mixing == 0) && i != 0 && a.C > 1;
+}
+__device__ __forceinline__ int swap_first(const DevSamplerArgs &a, long i, double *u_out) {  // MALA.cpp:397-405
+    double u, u2;
+    rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)i, 0, u, u2);
+    int A = (int)(u2 * (double)(a.C - 1));
+    if (A > a.C - 2) A = a.C - 2;
+    if (u_out) *u_out = u;
+    return A;
+}
+__device__ __forceinline__ bool in_swap_pair(const DevSamplerArgs &a, int c, long i) {
+    if (!is_swap_iter(a, i)) return false;
+    const int A = swap_first(a, i, nullptr);
+    return c == A || c == A + 1;
+}
+
+// Sums of the per-tile partials of chain c's candidates (wave w -> candidate w), in k_finalize's order: 256 strided
+// per-thread sums (four per lane here), shuffle tree per 64, the four in order.  No barrier inside.
+__device__ void spec_sums(const DevSamplerArgs &a, int c, int np, double *s_S) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w >= np) return;  // wave-uniform
+    const double *base = a.partials + (size_t)(c * a.D + w) * a.ntiles * 2;
+    double t1 = 0, t2 = 0;
+    for (int q = 0; q < TB / 64; q++) {
+        double s1 = 0, s2 = 0;
+        for (int t = q * 64 + lane; t < a.ntiles; t += TB) {
+            s1 = s1 + base[2 * t];
+            s2 = s2 + base[2 * t + 1];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s1 = s1 + __shfl_down(s1, off, 64);
+            s2 = s2 + __shfl_down(s2, off, 64);
+        }
+        if (q == 0) { t1 = s1; t2 = s2; }
+        else { t1 = t1 + s1; t2 = t2 + s2; }
+    }
+    if (lane == 0) s_S[w] = t1 + t2;
+}
+
+// thread 0: the MH tests of chain c's candidates, in order (same arithmetic as accept_result)
+__device__ void spec_tests(const DevSamplerArgs &a, int c, int P, int first, long it_a, const double *S, SpecOut &o) {
+    const int C = a.C, D = a.D;
+    long d = first ? it_a : a.sp_done[P * C + c];
+    const int np = first ? 0 : a.sp_nprop[P * C + c];
+    int ph = first ? 0 : a.sp_phase[P * C + c];
+    o.logL0 = a.logL_cur[P * C + c]; o.logPr0 = a.logPr_cur[P * C + c]; o.logPost0 = a.logPost_cur[P * C + c];
+    o.logL = o.logL0; o.logPr = o.logPr0; o.logPost = o.logPost0;
+    o.src_chain = c; o.src_cand = -1;
+    o.n_rec = 0; o.acc_last = 0; o.r_last = 0; o.resolved = 0; o.swapped = 0;
+    for (int k = 0; k < np; k++) {
+        const int slot = c * D + k;
+        double logL = (-(double)a.pl * S[k]) / a.Tcoefs[c];  // call_likelihood, model_def.cpp:399-401
+        const double logPr = a.logPr_prop[(size_t)P * C * D + slot];
+        double logPost;
+        if (a.status_prop[(size_t)P * C * D + slot] != TAMCMC_OK) logL = NAN;
+        if (logPr == -INFINITY || isnan(logPr)) { logL = a.init_logL[c]; logPost = -INFINITY; }  // model_def.cpp:476-480
+        else logPost = logL + logPr;
+        double u, u1;
+        rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)c, (uint64_t)d, 0, u, u1);
+        double r;
+        if (!isnan(logL)) {
+            if (logPost == -INFINITY) r = 0.;
+            else {
+                const double e = exp(logPost - o.logPost0);
+                r = fmin(1.0, e);
+                if (isnan(r)) r = 0.;
+            }
+        } else r = 0.;
+        const int acc = (u <= r) ? 1 : 0;
+        o.n_rec++;
+        d++;
+        o.r_last = r;
+        o.acc_last = acc;
+        if (acc) {
+            o.src_cand = k;
+            o.logL = logL; o.logPr = logPr; o.logPost = logPost;
+            break;
+        }
+    }
+    o.swap_last = (o.n_rec > 0 && in_swap_pair(a, c, d - 1)) ? 1 : 0;
+    if (o.swap_last) ph = 1;
+    o.done = d;
+    o.phase = ph;
+}
+
+__global__ void __launch_bounds__(TB) k_spec(const DevSamplerArgs a, const int P, const int first, const long it_a, const long it_b,
+                                            const long rec_base) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int Np = a.desc.Np, Nv = a.Nv, C = a.C, D = a.D;
+    double *s_params = (double *)s_raw;
+    double *s_vars = s_params + Np;
+    double *s_z = s_vars + Nv;
+    const UnpackLds U = carve_unpack_lds((unsigned char *)(s_z + Nv + 1));
+    __shared__ SpecOut s_me, s_pt;
+    __shared__ double s_S[4], s_Sp[4];
+
+    const int c = blockIdx.x / D, j = blockIdx.x - c * D, tid = threadIdx.x;
+    const int Q = P ^ 1;
+    const size_t CD = (size_t)C * D;
+
+    // ---- (0) this chain's MH tests
+    const int np = first ? 0 : a.sp_nprop[P * C + c];
+    spec_sums(a, c, np, s_S);
+    __syncthreads();
+    if (tid == 0) spec_tests(a, c, P, first, it_a, s_S, s_me);
+    __syncthreads();
+    // ---- (1) swap: both chains of the pair have tested iteration s -> resolve (each side recomputes the other's tests)
+    if (s_me.phase == 1) {  // workgroup-uniform
+        const long sidx = s_me.done - 1;
+        const int A = swap_first(a, sidx, nullptr);
+        const int partner = (c == A) ? A + 1 : A;
+        const int npp = first ? 0 : a.sp_nprop[P * C + partner];
+        spec_sums(a, partner, npp, s_Sp);
+        __syncthreads();
+        if (tid == 0) {
+            spec_tests(a, partner, P, first, it_a, s_Sp, s_pt);
+            if (s_pt.phase == 1 && s_pt.done == s_me.done) {
+                double u;
+                swap_first(a, sidx, &u);
+                const int B = A + 1;
+                const double LA = (c == A) ? s_me.logL : s_pt.logL;
+                const double LB = (c == A) ? s_pt.logL : s_me.logL;
+                const double LA_TB = LA * a.Tcoefs[A] / a.Tcoefs[B];
+                const double LB_TA = LB * a.Tcoefs[B] / a.Tcoefs[A];
+                const double e = exp(LA_TB + LB_TA - LA - LB);
+                const double rT = fmin(1.0, e);
+                const bool swapped = (u <= rT);
+                if (swapped) {
+                    s_me.src_chain = partner;
+                    s_me.src_cand = s_pt.src_cand;
+                    s_me.logPr = s_pt.logPr;
+                    s_me.logL = (c == A) ? LB_TA : LA_TB;  // re-tempered value of the partner's likelihood
+                    s_me.logPost = s_me.logL + s_me.logPr;
+                }
+                s_me.phase = 0;
+                s_me.resolved = 1;
+                s_me.swapped = swapped ? 1 : 0;
+                if (c == A && j == 0) {  // several pairs (of different iterations) may resolve in one round
+                    atomicAdd((unsigned long long *)&a.counters[2], 1ull);
+                    if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- (2) how many candidates the chain proposes now: none while it waits; none past the end of the stretch; none past a
+    //          swap step it takes part in
+    if (tid == 0) {
+        int n = 0;
+        if (s_me.phase == 0) {
+            for (int k = 0; k < D; k++) {
+                const long i = s_me.done + k;
+                if (i >= it_b) break;
+                n++;
+                if (in_swap_pair(a, c, i)) break;
+            }
+        }
+        s_me.nprop_new = n;
+    }
+    __syncthreads();
+    // ---- (3) the chain's state -> LDS (and, by the chain's first workgroup, -> the other parity buffer + records)
+    const double *curv = a.vars_cur + (size_t)P * C * Nv, *curp = a.params_cur + (size_t)P * C * Np;
+    const double *cndv = a.vars_prop + (size_t)P * CD * Nv, *cndp = a.params_prop + (size_t)P * CD * Np;
+    const int sc = s_me.src_chain, sk = s_me.src_cand;
+    const double *sv = (sk < 0) ? curv + (size_t)sc * Nv : cndv + ((size_t)sc * D + sk) * Nv;
+    const double *sp = (sk < 0) ? curp + (size_t)sc * Np : cndp + ((size_t)sc * D + sk) * Np;
+    for (int i = tid; i < Nv; i += TB) s_vars[i] = sv[i];
+    for (int i = tid; i < Np; i += TB) s_params[i] = sp[i];
+    __syncthreads();
+    if (j == 0) {
+        double *newv = a.vars_cur + (size_t)Q * C * Nv + (size_t)c * Nv, *newp = a.params_cur + (size_t)Q * C * Np + (size_t)c * Np;
+        for (int i = tid; i < Nv; i += TB) newv[i] = s_vars[i];
+        for (int i = tid; i < Np; i += TB) newp[i] = s_params[i];
+        // records (update_buffer_params / update_buffer_stat_criteria, MALA.cpp:708-710): rejected iterations hold the old
+        // state; the last tested iteration holds the new one when accepted; a swap step is recorded once the swap is resolved
+        const long d0 = s_me.done - s_me.n_rec;
+        const int deferred_now = s_me.swap_last;                        // the last tested iteration waits for the swap
+        const int last_new = (s_me.n_rec > 0 && (s_me.acc_last || deferred_now)) ? 1 : 0;
+        const int n_old = s_me.n_rec - last_new;
+        // final-state record: an accepted (non-swap) last iteration, or the swap step resolved in this round
+        const int rec_final = (s_me.n_rec > 0 && s_me.acc_last && !deferred_now) || s_me.resolved;
+        if (a.samples) {
+            const double *ov = curv + (size_t)c * Nv;
+            for (int t = 0; t < n_old; t++)
+                for (int i = tid; i < Nv; i += TB) a.samples[((size_t)(d0 + t - rec_base) * C + c) * Nv + i] = ov[i];
+            if (rec_final)
+                for (int i = tid; i < Nv; i += TB) a.samples[((size_t)(s_me.done - 1 - rec_base) * C + c) * Nv + i] = s_vars[i];
+        }
+        if (tid == 0) {
+            if (a.stats) {
+                for (int t = 0; t < n_old; t++) {
+                    double *r = a.stats + ((size_t)(d0 + t - rec_base) * C + c) * 3;
+                    r[0] = s_me.logL0; r[1] = s_me.logPr0; r[2] = s_me.logPost0;
+                }
+                if (rec_final) {
+                    double *r = a.stats + ((size_t)(s_me.done - 1 - rec_base) * C + c) * 3;
+                    r[0] = s_me.logL; r[1] = s_me.logPr; r[2] = s_me.logPost;
+                }
+            }
+            a.logL_cur[Q * C + c] = s_me.logL;
+            a.logPr_cur[Q * C + c] = s_me.logPr;
+            a.logPost_cur[Q * C + c] = s_me.logPost;
+            a.sp_done[Q * C + c] = s_me.done;
+            a.sp_nprop[Q * C + c] = s_me.nprop_new;
+            a.sp_phase[Q * C + c] = s_me.phase;
+            if (s_me.n_rec > 0) {
+                a.moved[c] = s_me.acc_last;
+                a.Pmove[c] = s_me.r_last;
+                if (c == 0 && s_me.acc_last) a.counters[1] += 1;
+            }
+            atomicAdd((unsigned long long *)&a.counters[4], (unsigned long long)s_me.nprop_new);  // candidates handed to the likelihood kernel
+        }
+    }
+    // ---- (4) candidate j: the proposal of iteration done+j, or an empty slot
+    const int slot = c * D + j;
+    if (j < s_me.nprop_new) {
+        propose_common(a, U, c, s_me.done + j, slot, a.vars_prop + ((size_t)Q * CD + slot) * Nv, a.params_prop + ((size_t)Q * CD + slot) * Np,
+                       a.logPr_prop + (size_t)Q * CD + slot, a.status_prop + (size_t)Q * CD + slot, s_vars, s_params, s_z,
+                       (a.dbg && c == 0 && j == 0) ? a.dbg : nullptr);
+    } else if (tid == 0) {
+        a.pairs[2 * slot] = slot * a.desc.per;
+        a.pairs[2 * slot + 1] = slot * a.desc.per;
+        a.nh[slot] = 0;
+        a.nn[slot] = 0;  // the likelihood kernel skips the slot
+    }
 }
 
 }  // namespace
@@ -401,6 +663,14 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     a.seed = in.seed; a.dN_mixing = in.dN_mixing;
     a.c0 = in.c0; a.epsilon1 = in.epsilon1; a.epsi2 = in.epsi2; a.A1 = in.A1; a.target_acceptance = in.target_acceptance;
     const size_t C = (size_t)in.C, Np = (size_t)in.Np, Nv = (size_t)in.Nv;
+    {  // candidate slots per chain of the speculative rounds (1 = one iteration per round everywhere)
+        const char *ed = getenv("TAMCMC_SPEC_DEPTH");
+        int D = ed ? atoi(ed) : 3;
+        if (D < 1) D = 1;
+        if (D > TB / 64) D = TB / 64;  // spec_sums: one wave per candidate
+        a.D = D;
+    }
+    const size_t CD = C * (size_t)a.D;
     hipStream_t st = c->stream;
     int *d_pl, *d_idx, *d_sw;
     double *d_pr, *d_ex, *d_T;
@@ -411,16 +681,17 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     a.desc.plength = d_pl; a.index_to_relax = d_idx; a.desc.priors_switch = d_sw; a.desc.priors = d_pr; a.desc.extra = d_ex; a.Tcoefs = d_T;
     // every per-iteration array exists twice (parity): a workgroup reads parity P and writes parity P^1
     DCHK(I.dalloc(&a.vars_cur, 2 * C * Nv)); DCHK(I.dalloc(&a.params_cur, 2 * C * Np));
-    DCHK(I.dalloc(&a.vars_prop, 2 * C * Nv)); DCHK(I.dalloc(&a.params_prop, 2 * C * Np));
+    DCHK(I.dalloc(&a.vars_prop, 2 * CD * Nv)); DCHK(I.dalloc(&a.params_prop, 2 * CD * Np));
     DCHK(I.dalloc(&a.logL_cur, 2 * C)); DCHK(I.dalloc(&a.logPr_cur, 2 * C)); DCHK(I.dalloc(&a.logPost_cur, 2 * C));
-    DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * C)); DCHK(I.dalloc(&a.status_prop, 2 * C));
-    DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 4));
+    DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * CD)); DCHK(I.dalloc(&a.status_prop, 2 * CD));
+    DCHK(I.dalloc(&a.sp_done, 2 * C)); DCHK(I.dalloc(&a.sp_nprop, 2 * C)); DCHK(I.dalloc(&a.sp_phase, 2 * C));
+    DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8));
     a.dbg = nullptr;
     if (getenv("TAMCMC_DEBUG_STAMPS")) { DCHK(I.dalloc(&a.dbg, 16)); DCHK(hipMemsetAsync(a.dbg, 0, 16 * sizeof(long), st)); }
     DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
-    DCHK(I.dalloc(&a.mults, C * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * C)); DCHK(I.dalloc(&a.nh, C)); DCHK(I.dalloc(&a.nn, C));
-    DCHK(I.dalloc(&a.noise, C * (size_t)a.desc.stride));
-    DCHK(hipMemsetAsync(a.counters, 0, 4 * sizeof(long), st));
+    DCHK(I.dalloc(&a.mults, CD * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * CD)); DCHK(I.dalloc(&a.nh, CD)); DCHK(I.dalloc(&a.nn, CD));
+    DCHK(I.dalloc(&a.noise, CD * (size_t)a.desc.stride));
+    DCHK(hipMemsetAsync(a.counters, 0, 8 * sizeof(long), st));
     DCHK(hipMemsetAsync(a.moved, 0, C * sizeof(int), st));
     DCHK(hipMemsetAsync(a.Pmove, 0, C * sizeof(double), st));
     a.samples = nullptr; a.stats = nullptr;
@@ -433,6 +704,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
         DCHK(hipFuncSetAttribute((const void *)k_iterate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(I.lds_base + I.lds_adapt)));
         DCHK(hipFuncSetAttribute((const void *)k_iterate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(I.lds_base + I.lds_adapt)));
     }
+    if (I.lds_base > 64 * 1024) DCHK(hipFuncSetAttribute((const void *)k_spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_base));
     // polynomial tables Pslm/Qlm: computed ON the device (its own double arithmetic), read through a uniform pointer
     mt::PolyTab *d_tab;
     DCHK(I.dalloc(&d_tab, 1));
@@ -541,6 +813,7 @@ int DevSampler::download_proposal(int m, double *cov, double *mu, double *sigma)
 }
 
 // n_iter iterations starting at iteration counter `it0`; learn[i] != 0 -> adaptation after iteration it0+i.
+// Stretches without adaptation run as speculative rounds (k_spec); the others one iteration per round (k_iterate).
 int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, double *stats) {
     Impl &I = *impl;
     tamcmc_hip_ctx *c = I.ctx;
@@ -549,9 +822,10 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     DCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t C = (size_t)a.C, Nv = (size_t)a.Nv;
+    const int D = a.D;
     const int tb = tile_bins(c->wgs, c->K);
     a.ntiles = (a.desc.Nx + tb - 1) / tb;
-    DCHK(c->d_part.reserve(C * (size_t)a.ntiles * 2));
+    DCHK(c->d_part.reserve(C * (size_t)D * (size_t)a.ntiles * 2));
     a.partials = c->d_part.p;
     if (samples && I.smp_cap < (size_t)n_iter * C * Nv) {
         DCHK(I.dalloc(&a.samples, (size_t)n_iter * C * Nv));  // (older, smaller buffers are released with the sampler)
@@ -569,77 +843,181 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     int goff[5];
     for (int g = 0; g <= G; g++) goff[g] = (int)(((long)a.C * g) / G);
     auto group_of = [&](int chain) { int g = 0; while (g + 1 < G && chain >= goff[g + 1]) g++; return g; };
-    LoglikeArgs la[4];
-    for (int g = 0; g < G; g++) {
-        LoglikeArgs &l = la[g];
-        const int co = goff[g];
-        l.x = c->dx.p; l.y = c->dy.p; l.logx = c->dlogx.p; l.Nx = a.desc.Nx; l.B = goff[g + 1] - co; l.ntiles = a.ntiles;
+    LoglikeArgs la[4], las;
+    auto fill_la = [&](LoglikeArgs &l, int first_slot, int nslots, bool stamps) {
+        l.x = c->dx.p; l.y = c->dy.p; l.logx = c->dlogx.p; l.Nx = a.desc.Nx; l.B = nslots; l.ntiles = a.ntiles;
         l.x0 = a.desc.x_first; l.step = a.desc.step;
-        l.mults = a.mults; l.offsets = a.pairs + 2 * co; l.noise = a.noise + (size_t)co * a.desc.stride; l.noise_stride = a.desc.stride;
-        l.nharvey = a.nh + co; l.nnoise = a.nn + co; l.partials = a.partials + (size_t)co * a.ntiles * 2; l.model = nullptr;
-        l.dbg = (a.dbg && g == 0) ? a.dbg + 8 : nullptr;
+        l.mults = a.mults; l.offsets = a.pairs + 2 * first_slot; l.noise = a.noise + (size_t)first_slot * a.desc.stride; l.noise_stride = a.desc.stride;
+        l.nharvey = a.nh + first_slot; l.nnoise = a.nn + first_slot; l.partials = a.partials + (size_t)first_slot * a.ntiles * 2; l.model = nullptr;
+        l.dbg = (a.dbg && stamps) ? a.dbg + 8 : nullptr;
         l.tile_rot = I.tile_rot;
-    }
-    // the extra streams start after everything already enqueued on the context stream
-    DCHK(hipEventRecord(I.ev_fork, st));
-    for (int g = 1; g < G; g++) DCHK(hipStreamWaitEvent(I.gst[g], I.ev_fork, 0));
+    };
+    for (int g = 0; g < G; g++) fill_la(la[g], goff[g], goff[g + 1] - goff[g], g == 0);
+    fill_la(las, 0, a.C * D, true);
+
     int used_ev = 0;
-    const long ev_every = n_iter > 64 ? n_iter / 64 : 1;
-    int P = I.parity, pending = 0;
-    for (long i = 0; i <= n_iter; i++) {
-        const long it = it0 + i;
-        const int learn_p = (pending && learn && learn[i - 1]) ? 1 : 0;
-        const size_t lds = I.lds_base + ((learn_p && a.chol_in_lds) ? I.lds_adapt : 0);
-        const long rec = (pending && (samples || stats)) ? i - 1 : (long)-1;
-        // does settling iteration it-1 swap a pair that straddles two groups? (same draw as the kernel: Philox is host/device)
-        int gA = -1, gB = -1;
-        if (pending && G > 1) {
-            const long itp = it - 1;
-            if (a.dN_mixing > 0 && (itp % a.dN_mixing == 0) && itp != 0 && a.C > 1) {
-                double u, u2;
-                rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)itp, 0, u, u2);
-                int A = (int)(u2 * (double)(a.C - 1));
-                if (A > a.C - 2) A = a.C - 2;
-                if (group_of(A) != group_of(A + 1)) { gA = group_of(A); gB = group_of(A + 1); }
+    int P = I.parity;
+    double kernel_ms = 0;
+    long n_launch = 0, n_eval = 0;
+    auto drain_events = [&](double launches_represented, long evals) -> int {  // call after a stream sync
+        if (used_ev) {
+            double tot = 0;
+            for (int e = 0; e < used_ev; e++) {
+                float ms = 0;
+                DCHK(hipEventElapsedTime(&ms, I.ev[e][0], I.ev[e][1]));
+                tot += ms;
             }
+            kernel_ms += tot / used_ev * launches_represented;
+            n_launch += (long)launches_represented;
+            n_eval += evals;
         }
-        if (gA >= 0) {  // each of the two groups needs the other's k_loglike(it-1) before it settles the pair
-            DCHK(hipEventRecord(I.ev_kb[gA], I.gst[gA]));
-            DCHK(hipEventRecord(I.ev_kb[gB], I.gst[gB]));
-            DCHK(hipStreamWaitEvent(I.gst[gA], I.ev_kb[gB], 0));
-            DCHK(hipStreamWaitEvent(I.gst[gB], I.ev_kb[gA], 0));
-        }
-        for (int g = 0; g < G; g++) {
-            const int cnt = goff[g + 1] - goff[g];
-            if (i < n_iter)
-                hipLaunchKernelGGL(k_iterate<true>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
-            else  // settle the last iteration of this run (MH test, swap, record, adaptation); nothing is proposed
-                hipLaunchKernelGGL(k_iterate<false>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
-        }
-        if (gA >= 0) {  // ... and must not overwrite (next iteration) what the other group's settle is still reading
-            DCHK(hipEventRecord(I.ev_ki[gA], I.gst[gA]));
-            DCHK(hipEventRecord(I.ev_ki[gB], I.gst[gB]));
-            DCHK(hipStreamWaitEvent(I.gst[gA], I.ev_ki[gB], 0));
-            DCHK(hipStreamWaitEvent(I.gst[gB], I.ev_ki[gA], 0));
-        }
-        P ^= 1;
-        pending = 1;
-        if (i < n_iter) {
+        used_ev = 0;
+        return TAMCMC_OK;
+    };
+
+    // ---- one iteration per round over [ia, ib): k_iterate settles iteration it-1 and proposes iteration it
+    auto lockstep = [&](long ia, long ib) -> int {
+        // the extra streams start after everything already enqueued on the context stream
+        DCHK(hipEventRecord(I.ev_fork, st));
+        for (int g = 1; g < G; g++) DCHK(hipStreamWaitEvent(I.gst[g], I.ev_fork, 0));
+        const long len = ib - ia;
+        const long ev_every = len > 32 ? len / 32 : 1;
+        int pending = 0;
+        for (long i = ia; i <= ib; i++) {
+            const long it = it0 + i;
+            const int learn_p = (pending && learn && learn[i - 1]) ? 1 : 0;
+            const size_t lds = I.lds_base + ((learn_p && a.chol_in_lds) ? I.lds_adapt : 0);
+            const long rec = (pending && (samples || stats)) ? i - 1 : (long)-1;
+            // does settling iteration it-1 swap a pair that straddles two groups? (same draw as the kernel: Philox is host/device)
+            int gA = -1, gB = -1;
+            if (pending && G > 1) {
+                const long itp = it - 1;
+                if (a.dN_mixing > 0 && (itp % a.dN_mixing == 0) && itp != 0 && a.C > 1) {
+                    double u, u2;
+                    rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)itp, 0, u, u2);
+                    int A = (int)(u2 * (double)(a.C - 1));
+                    if (A > a.C - 2) A = a.C - 2;
+                    if (group_of(A) != group_of(A + 1)) { gA = group_of(A); gB = group_of(A + 1); }
+                }
+            }
+            if (gA >= 0) {  // each of the two groups needs the other's k_loglike(it-1) before it settles the pair
+                DCHK(hipEventRecord(I.ev_kb[gA], I.gst[gA]));
+                DCHK(hipEventRecord(I.ev_kb[gB], I.gst[gB]));
+                DCHK(hipStreamWaitEvent(I.gst[gA], I.ev_kb[gB], 0));
+                DCHK(hipStreamWaitEvent(I.gst[gB], I.ev_kb[gA], 0));
+            }
             for (int g = 0; g < G; g++) {
-                const bool timed = g == 0 && c->timing && (i % ev_every == 0) && used_ev < I.n_ev;
-                if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], I.gst[g]));
-                DCHK(launch_loglike(la[g], c->precision, c->wgs, c->K, false, I.gst[g]));
-                if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], I.gst[g])); used_ev++; }
+                const int cnt = goff[g + 1] - goff[g];
+                if (i < ib)
+                    hipLaunchKernelGGL(k_iterate<true>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
+                else  // settle the last iteration of this stretch (MH test, swap, record, adaptation); nothing is proposed
+                    hipLaunchKernelGGL(k_iterate<false>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
+            }
+            if (gA >= 0) {  // ... and must not overwrite (next iteration) what the other group's settle is still reading
+                DCHK(hipEventRecord(I.ev_ki[gA], I.gst[gA]));
+                DCHK(hipEventRecord(I.ev_ki[gB], I.gst[gB]));
+                DCHK(hipStreamWaitEvent(I.gst[gA], I.ev_ki[gB], 0));
+                DCHK(hipStreamWaitEvent(I.gst[gB], I.ev_ki[gA], 0));
+            }
+            P ^= 1;
+            pending = 1;
+            if (i < ib) {
+                for (int g = 0; g < G; g++) {
+                    const bool timed = g == 0 && c->timing && ((i - ia) % ev_every == 0) && used_ev < I.n_ev;
+                    if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], I.gst[g]));
+                    DCHK(launch_loglike(la[g], c->precision, c->wgs, c->K, false, I.gst[g]));
+                    if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], I.gst[g])); used_ev++; }
+                }
             }
         }
+        // join: the context stream continues after every group
+        for (int g = 1; g < G; g++) {
+            DCHK(hipEventRecord(I.ev_join[g], I.gst[g]));
+            DCHK(hipStreamWaitEvent(st, I.ev_join[g], 0));
+        }
+        DCHK(hipStreamSynchronize(st));
+        // (with chain groups every launch carries C/G evaluations and overlaps the other groups' kernels)
+        return drain_events((double)len * G, len * (long)a.C);
+    };
+
+    // ---- speculative rounds over [ia, ib) (no adaptation inside): every chain ends having completed iteration ib-1
+    auto speculative = [&](long ia, long ib) -> int {
+        const long it_a = it0 + ia, it_b = it0 + ib;
+        std::vector<long> h_done(C);
+        std::vector<int> h_np(C), h_ph(C);
+        long cand0 = 0, cand1 = 0;
+        DCHK(hipMemcpyAsync(&cand0, a.counters + 4, sizeof(long), hipMemcpyDeviceToHost, st));
+        int first = 1;
+        long remaining = ib - ia, rounds_total = 0;
+        // expected iterations per round at the target acceptance rate: 1 + q + q^2 + ... (q = rejection probability)
+        double rate = 0, q = 1.0;
+        for (int k = 0; k < D; k++) { rate += q; q *= (1.0 - a.target_acceptance); }
+        for (int batch = 0; batch < 1000000; batch++) {
+            long rounds = (long)((double)remaining / rate) + 2;
+            const long ev_every = rounds > 16 ? rounds / 16 : 1;
+            for (long r = 0; r < rounds; r++) {
+                hipLaunchKernelGGL(k_spec, dim3(a.C * D), dim3(TB), I.lds_base, st, args, P, first, it_a, it_b, it0);
+                first = 0;
+                P ^= 1;
+                const bool timed = c->timing && (r % ev_every == 0) && used_ev < I.n_ev;
+                if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
+                DCHK(launch_loglike(las, c->precision, c->wgs, c->K, false, st));
+                if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
+            }
+            rounds_total += rounds;
+            DCHK(hipMemcpyAsync(h_done.data(), a.sp_done + (size_t)P * C, C * sizeof(long), hipMemcpyDeviceToHost, st));
+            DCHK(hipMemcpyAsync(h_np.data(), a.sp_nprop + (size_t)P * C, C * sizeof(int), hipMemcpyDeviceToHost, st));
+            DCHK(hipMemcpyAsync(h_ph.data(), a.sp_phase + (size_t)P * C, C * sizeof(int), hipMemcpyDeviceToHost, st));
+            DCHK(hipMemcpyAsync(&cand1, a.counters + 4, sizeof(long), hipMemcpyDeviceToHost, st));
+            DCHK(hipStreamSynchronize(st));
+            DCHK(hipGetLastError());
+            int rc = drain_events((double)rounds, 0);
+            if (rc) return rc;
+            long min_done = it_b;
+            bool settled = true;
+            for (size_t m = 0; m < C; m++) {
+                if (h_done[m] < min_done) min_done = h_done[m];
+                if (h_np[m] != 0 || h_ph[m] != 0) settled = false;
+            }
+            if (min_done >= it_b && settled) break;
+            remaining = it_b - min_done;
+            if (remaining < 1) remaining = 1;
+        }
+        n_eval += cand1 - cand0;
+        (void)rounds_total;
+        return TAMCMC_OK;
+    };
+
+    // ---- split [0, n_iter) into stretches: quiet ones (no adaptation, at least MIN_SPEC long) run speculatively
+    const long MIN_SPEC = 8;  // shorter quiet stretches are not worth the drain rounds
+    auto quiet_end = [&](long from) { long q2 = from; while (q2 < n_iter && !(learn && learn[q2])) q2++; return q2; };
+    long i = 0;
+    while (i < n_iter) {
+        const long jn = quiet_end(i);
+        if (D > 1 && jn - i >= MIN_SPEC) {
+            int rc = speculative(i, jn);
+            if (rc) return rc;
+            i = jn;
+            continue;
+        }
+        long k = i;  // one iteration per round up to the start of the next long quiet stretch
+        for (;;) {
+            const long q2 = quiet_end(k);
+            if (D > 1 && q2 - k >= MIN_SPEC && k > i) break;
+            k = q2;
+            while (k < n_iter && learn && learn[k]) k++;
+            if (k >= n_iter) break;
+        }
+        int rc = lockstep(i, k);
+        if (rc) return rc;
+        i = k;
     }
-    // join: the context stream continues after every group
-    for (int g = 1; g < G; g++) {
-        DCHK(hipEventRecord(I.ev_join[g], I.gst[g]));
-        DCHK(hipStreamWaitEvent(st, I.ev_join[g], 0));
+    {  // iteration counter as the one-iteration engine leaves it
+        const long itn = it0 + n_iter;
+        DCHK(hipMemcpyAsync(a.counters, &itn, sizeof(long), hipMemcpyHostToDevice, st));
     }
     I.parity = P;
-    if (a.dbg) {  // phase stamps of the last k_iterate<true> launch (100 MHz wall clock), workgroup 0
+    if (a.dbg) {  // phase stamps of the last proposal workgroup of chain 0 / the middle tile (100 MHz wall clock)
         long h[16];
         DCHK(hipMemcpyAsync(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost, st));
         DCHK(hipStreamSynchronize(st));
@@ -653,19 +1031,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
     DCHK(hipStreamSynchronize(st));
-    if (used_ev) {
-        double tot = 0;
-        for (int e = 0; e < used_ev; e++) {
-            float ms = 0;
-            DCHK(hipEventElapsedTime(&ms, I.ev[e][0], I.ev[e][1]));
-            tot += ms;
-        }
-        // extrapolate the sampled launches to all launches of this run (every launch has the same shape)
-        // (with chain groups every launch carries C/G evaluations and overlaps the other groups' kernels)
-        c->kernel_ms += tot / used_ev * (double)n_iter * I.G;
-        c->launches += n_iter * I.G;
-        c->evals += n_iter * a.C;
-    }
+    c->kernel_ms += kernel_ms;
+    c->launches += n_launch;
+    c->evals += n_eval;
     return TAMCMC_OK;
 }
 

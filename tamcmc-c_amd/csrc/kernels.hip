@@ -248,6 +248,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     // that the long-running tiles (near field) are dispatched first and the cheap far-field-only tiles fill the tail
     int tile = (j / a.B) * 8 + xcd;
     if (tile >= a.ntiles) return;  // whole workgroup leaves before any barrier
+    if (a.nnoise[b] <= 0) return;  // empty evaluation slot (device sampler: a candidate that was not proposed)
     tile += a.tile_rot;
     if (tile >= a.ntiles) tile -= a.ntiles;
 
