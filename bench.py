@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--mala-steps", type=int, default=30, help="extra MALA-FD measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
     return ap.parse_args()
 
 
@@ -120,7 +121,7 @@ def main():
     def make_sampler(use_drift, learn_until):
         eng = "host" if use_drift else a.engine   # the Langevin drift runs on the host-driven engine
         return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=eng,
-                           Nt_learn=(max(learn_until // 2, 1), max(learn_until, 2)), periods_learn=(1,), dN_mixing=1)
+                           Nt_learn=(max(learn_until // 2, 1), max(learn_until, 2)), periods_learn=(1,), dN_mixing=a.dn_mixing)
 
     from tamcmc_c_amd import shard
     smp = make_sampler(1 if a.sampler == "mala" else 0, a.warmup)

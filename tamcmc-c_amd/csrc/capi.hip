@@ -131,6 +131,11 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
         const tamcmc_multiplet *hm = (const tamcmc_multiplet *)(c->h_stage.p + L.off_mults);
         a.tile_rot = tamcmc::pick_tile_rot(hm + pairs[0], pairs[1] - pairs[0], a.x0, a.step, tb, ntiles);
     }
+    if (c->precision == TAMCMC_PRECISION_FAST) {  // background series per (evaluation, tile), built once instead of per workgroup
+        HIPCHK(c, c->d_bg.reserve((size_t)B * ntiles * 8));
+        HIPCHK(c, tamcmc::launch_bg_poly(a, c->wgs, c->K, c->d_bg.p, st));
+        a.bg_poly = c->d_bg.p;
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
     HIPCHK(c, tamcmc::launch_loglike(a, c->precision, c->wgs, c->K, model != nullptr, st));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));

@@ -31,11 +31,14 @@ struct DevSamplerArgs {
     long *counters;       // [0] iteration, [1] accepted moves of chain 0, [2] swap attempts, [3] swaps accepted
     // proposal law
     double *LT, *cov, *mu, *sigma;   // LT = transposed Cholesky factor of (cov+eps2)*sigma
+    double *lz;           // [2][C][Nv] L z of the NEXT iteration, computed ahead by spare workgroups while L is frozen
     // likelihood-kernel input block written by k_propose_unpack
     tamcmc_multiplet *mults;
     int *pairs, *nh, *nn;
     double *noise;
     double *partials;
+    double *bg;           // [C*D x ntiles x 8] background series per (slot, tile), FAST far field only (else nullptr)
+    int tile_bins;
     // records
     double *samples, *stats;
     // speculative rounds (k_spec): D candidate slots per chain; per-chain progress, parity-doubled like the chain state

@@ -173,25 +173,34 @@ __device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const doub
     __syncthreads();
 }
 
-// Proposal of iteration `it` for `chain` from the state in LDS (s_vars/s_params): x' = x + L z (MALA.cpp:348-355), L =
-// chol((Sigma+eps2) sigma) stored transposed, same Philox streams as the host engine; log-prior; params' -> multiplet table
-// written into slot `slot` of the likelihood kernel's input block.  Ends without a barrier.
-__device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int chain, long it, int slot, double *pv, double *pp,
-                               double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, long *dbg) {
-    const int Np = a.desc.Np, Nv = a.Nv, tid = threadIdx.x;
-#define PSTAMP(k) do { if (dbg && tid == 0) dbg[k] = (long)wall_clock64(); } while (0)
-    for (int k2 = tid; 2 * k2 < Nv; k2 += TB) {
+// z ~ N(0, I) of (chain, iteration) into LDS (ends without a barrier) and row i of L z (MALA.cpp:348-355)
+__device__ __forceinline__ void normals_into(const DevSamplerArgs &a, int chain, long it, double *s_z) {
+    for (int k2 = threadIdx.x; 2 * k2 < a.Nv; k2 += TB) {
         double z0, z1;
         rng_normal2(a.seed, RNG_PROPOSAL, (uint32_t)chain, (uint64_t)it, (uint32_t)k2, z0, z1);
         s_z[2 * k2] = z0;
         s_z[2 * k2 + 1] = z1;
     }
-    unpack_begin(a.desc, U);
+}
+__device__ __forceinline__ double Lz_row(const DevSamplerArgs &a, int chain, int i, const double *s_z) {
+    const double *LT = a.LT + (size_t)chain * a.Nv * a.Nv;
+    double s = 0;
+    for (int k = 0; k <= i; k++) s = s + LT[(size_t)k * a.Nv + i] * s_z[k];
+    return s;
+}
 
-    const double *LT = a.LT + (size_t)chain * Nv * Nv;
+// Proposal of iteration `it` for `chain` from the state in LDS (s_vars/s_params): x' = x + L z (MALA.cpp:348-355), L =
+// chol((Sigma+eps2) sigma) stored transposed, same Philox streams as the host engine; log-prior; params' -> multiplet table
+// written into slot `slot` of the likelihood kernel's input block.  Ends without a barrier.
+__device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int chain, long it, int slot, double *pv, double *pp,
+                               double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, long *dbg,
+                               const double *lz = nullptr) {
+    const int Np = a.desc.Np, Nv = a.Nv, tid = threadIdx.x;
+#define PSTAMP(k) do { if (dbg && tid == 0) dbg[k] = (long)wall_clock64(); } while (0)
+    if (!lz) normals_into(a, chain, it, s_z);
+    unpack_begin(a.desc, U);
     for (int i = tid; i < Nv; i += TB) {  // lane i owns row i: reads s_vars[i] only, every s_z[k]
-        double s = 0;
-        for (int k = 0; k <= i; k++) s = s + LT[(size_t)k * Nv + i] * s_z[k];
+        const double s = lz ? lz[i] : Lz_row(a, chain, i, s_z);
         const double v = s_vars[i] + 0.0 + s;
         s_vars[i] = v;
         pv[i] = v;
@@ -208,6 +217,7 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
     const bool live = (logPr != -INFINITY) && !isnan(logPr);  // model_def.cpp:472,476-480
     TablePtrs T;
     T.mults = a.mults; T.pairs = a.pairs; T.nh = a.nh; T.nn = a.nn; T.noise = a.noise;
+    T.bg = a.bg; T.ntiles = a.ntiles; T.tile_bins = a.tile_bins;
     wg_unpack(a.desc, s_params, U, slot, T, live);
     if (tid == 0) {
         *logPr_out = logPr;
@@ -224,9 +234,20 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
 //   (1) proposes iteration `it` from that state: x' = x + L z, log-prior, params' -> multiplet table.
 template <bool PROPOSE>
 __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const long it, const int P, const int pending,
-                                               const long rec, const int learn_pending, double *scratch, const int c_off) {
+                                               const long rec, const int learn_pending, double *scratch, const int c_off,
+                                               const int nmain, const int pre_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int Np = a.desc.Np, Nv = a.Nv, C = a.C;
+    if ((int)blockIdx.x >= nmain) {
+        // spare workgroup (launched while no adaptation touches L): L z of iteration it+1 for chain c_off + blockIdx.x - nmain
+        const int ch = c_off + (int)blockIdx.x - nmain;
+        double *z = (double *)s_raw;
+        normals_into(a, ch, it + 1, z);
+        __syncthreads();
+        double *dst = a.lz + ((size_t)((it + 1) & 1) * C + ch) * Nv;
+        for (int i = threadIdx.x; i < Nv; i += TB) dst[i] = Lz_row(a, ch, i, z);
+        return;
+    }
     double *s_params = (double *)s_raw;          // [Np]   current, then proposed parameter vector
     double *s_vars = s_params + Np;              // [Nv]   current, then proposed variables
     double *s_z = s_vars + Nv;                   // [Nv+1] normals / post-test position for the adaptation
@@ -324,7 +345,8 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
 
     // ------------------------------------------------------------------ (1) propose iteration `it`
     propose_common(a, U, m, it, m, a.vars_prop + (size_t)Q * C * Nv + (size_t)m * Nv, a.params_prop + (size_t)Q * C * Np + (size_t)m * Np,
-                   a.logPr_prop + Q * C + m, a.status_prop + Q * C + m, s_vars, s_params, s_z, (a.dbg && m == 0) ? a.dbg : nullptr);
+                   a.logPr_prop + Q * C + m, a.status_prop + Q * C + m, s_vars, s_params, s_z, (a.dbg && m == 0) ? a.dbg : nullptr,
+                   (pre_flags & 1) ? a.lz + ((size_t)(it & 1) * C + m) * Nv : nullptr);
 #undef STAMP
 }
 
@@ -597,6 +619,7 @@ struct DevSampler::Impl {
     int parity = 0;  // which of the two state buffers holds the chains' current state
     // chain groups: the chains are split into G contiguous groups, each on its own stream, so that one group's k_iterate
     // overlaps the other groups' k_loglike (an iteration is a serial k_iterate -> k_loglike chain per group)
+    bool pre_lz = true;  // spare workgroups compute L z one iteration ahead (TAMCMC_PRE_LZ=0 disables)
     int tile_rot = 0;  // launch-order hint of k_loglike (first near-field tile of chain 0's initial table)
     std::vector<int32_t> h_plength;
     int G = 1;
@@ -665,7 +688,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     const size_t C = (size_t)in.C, Np = (size_t)in.Np, Nv = (size_t)in.Nv;
     {  // candidate slots per chain of the speculative rounds (1 = one iteration per round everywhere)
         const char *ed = getenv("TAMCMC_SPEC_DEPTH");
-        int D = ed ? atoi(ed) : 3;
+        int D = ed ? atoi(ed) : 1;  // measured on MI355X (C3, 20 chains): extra candidates cost ~1 us each, more than they save
         if (D < 1) D = 1;
         if (D > TB / 64) D = TB / 64;  // spec_sums: one wave per candidate
         a.D = D;
@@ -688,7 +711,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8));
     a.dbg = nullptr;
     if (getenv("TAMCMC_DEBUG_STAMPS")) { DCHK(I.dalloc(&a.dbg, 16)); DCHK(hipMemsetAsync(a.dbg, 0, 16 * sizeof(long), st)); }
-    DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
+    DCHK(I.dalloc(&a.lz, 2 * C * Nv)); DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, CD * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * CD)); DCHK(I.dalloc(&a.nh, CD)); DCHK(I.dalloc(&a.nn, CD));
     DCHK(I.dalloc(&a.noise, CD * (size_t)a.desc.stride));
     DCHK(hipMemsetAsync(a.counters, 0, 8 * sizeof(long), st));
@@ -713,6 +736,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     a.desc.poly = d_tab;
     for (int i = 0; i < 64; i++) { DCHK(hipEventCreate(&I.ev[i][0])); DCHK(hipEventCreate(&I.ev[i][1])); I.n_ev = i + 1; }
     {
+        if (const char *ep = getenv("TAMCMC_PRE_LZ")) I.pre_lz = atoi(ep) != 0;
         const char *eg = getenv("TAMCMC_CHAIN_GROUPS");
         int G = eg ? atoi(eg) : (in.C >= 8 ? 2 : 1);
         if (G < 1) G = 1;
@@ -827,6 +851,12 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     a.ntiles = (a.desc.Nx + tb - 1) / tb;
     DCHK(c->d_part.reserve(C * (size_t)D * (size_t)a.ntiles * 2));
     a.partials = c->d_part.p;
+    a.tile_bins = tb;
+    a.bg = nullptr;
+    if (c->precision == TAMCMC_PRECISION_FAST) {
+        DCHK(c->d_bg.reserve(C * (size_t)D * (size_t)a.ntiles * 8));
+        a.bg = c->d_bg.p;
+    }
     if (samples && I.smp_cap < (size_t)n_iter * C * Nv) {
         DCHK(I.dalloc(&a.samples, (size_t)n_iter * C * Nv));  // (older, smaller buffers are released with the sampler)
         I.smp_cap = (size_t)n_iter * C * Nv;
@@ -851,6 +881,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         l.nharvey = a.nh + first_slot; l.nnoise = a.nn + first_slot; l.partials = a.partials + (size_t)first_slot * a.ntiles * 2; l.model = nullptr;
         l.dbg = (a.dbg && stamps) ? a.dbg + 8 : nullptr;
         l.tile_rot = I.tile_rot;
+        l.bg_poly = a.bg ? a.bg + (size_t)first_slot * a.ntiles * 8 : nullptr;
     };
     for (int g = 0; g < G; g++) fill_la(la[g], goff[g], goff[g + 1] - goff[g], g == 0);
     fill_la(las, 0, a.C * D, true);
@@ -882,10 +913,14 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         for (int g = 1; g < G; g++) DCHK(hipStreamWaitEvent(I.gst[g], I.ev_fork, 0));
         const long len = ib - ia;
         const long ev_every = len > 32 ? len / 32 : 1;
-        int pending = 0;
+        int pending = 0, have_pre = 0;
         for (long i = ia; i <= ib; i++) {
             const long it = it0 + i;
             const int learn_p = (pending && learn && learn[i - 1]) ? 1 : 0;
+            // L z of iteration it+1 can be computed by spare workgroups of THIS launch when no adaptation rewrites L in this
+            // launch (learn_p) nor in the next one before its proposal (learn[i])
+            const int make_pre = (I.pre_lz && i + 1 < ib && !learn_p && !(learn && learn[i])) ? 1 : 0;
+            const int pre_flags = (have_pre ? 1 : 0) | (make_pre ? 2 : 0);
             const size_t lds = I.lds_base + ((learn_p && a.chol_in_lds) ? I.lds_adapt : 0);
             const long rec = (pending && (samples || stats)) ? i - 1 : (long)-1;
             // does settling iteration it-1 swap a pair that straddles two groups? (same draw as the kernel: Philox is host/device)
@@ -909,10 +944,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             for (int g = 0; g < G; g++) {
                 const int cnt = goff[g + 1] - goff[g];
                 if (i < ib)
-                    hipLaunchKernelGGL(k_iterate<true>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
+                    hipLaunchKernelGGL(k_iterate<true>, dim3(make_pre ? 2 * cnt : cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p,
+                                       I.adapt_scratch, goff[g], cnt, pre_flags);
                 else  // settle the last iteration of this stretch (MH test, swap, record, adaptation); nothing is proposed
-                    hipLaunchKernelGGL(k_iterate<false>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch, goff[g]);
+                    hipLaunchKernelGGL(k_iterate<false>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch,
+                                       goff[g], cnt, 0);
             }
+            have_pre = make_pre;
             if (gA >= 0) {  // ... and must not overwrite (next iteration) what the other group's settle is still reading
                 DCHK(hipEventRecord(I.ev_ki[gA], I.gst[gA]));
                 DCHK(hipEventRecord(I.ev_ki[gB], I.gst[gB]));

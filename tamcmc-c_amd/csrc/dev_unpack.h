@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "bg_series.h"
 #include "mode_tables_impl.h"
 #include "priors_impl.h"
 
@@ -23,6 +24,8 @@ struct TablePtrs {  // the likelihood kernel's input block
     tamcmc_multiplet *mults;
     int *pairs, *nh, *nn;
     double *noise;
+    double *bg = nullptr;      // [slots x ntiles x 8] background series per (slot, tile) for the FAST far field, or nullptr
+    int ntiles = 0, tile_bins = 0;
 };
 
 // LDS scratch of the cooperative routines: 8 + 40 doubles, a PolyTab, a Shared, 4 ints/doubles
@@ -166,6 +169,23 @@ __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, con
             if (st) *u.status = st;
         }
         for (int i = tid; i < S->L.Nnoise; i += nt) T.noise[(size_t)slot * d.stride + i] = fabs(s_params[S->L.o_noise + i]);
+        if (T.bg) {
+            // background series of every tile (bg_series.h): the lanes beyond the first wave, which builds the multiplets
+            const int first = (nt > 64) ? 64 : 0, nw = nt - first;
+            const double *np_ = s_params + S->L.o_noise;
+            const int nh = S->nharvey, nn = S->L.Nnoise;
+            if (tid >= first)
+                for (int t = tid - first; t < T.ntiles; t += nw) {
+                    double xc, h;
+                    bg::tile_geometry(t, T.tile_bins, d.x_first, d.step, xc, h);
+                    if (!bg::series_valid(xc, h)) continue;
+                    double o[bg::NH];
+                    bg::tile_series([np_](int i) { return fabs(np_[i]); }, nh, nn, xc, h, o);
+                    double *dst = T.bg + ((size_t)slot * T.ntiles + t) * bg::NH;
+#pragma unroll
+                    for (int k = 0; k < bg::NH; k++) dst[k] = o[k];
+                }
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -176,6 +196,11 @@ __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, con
         T.nn[slot] = ok ? S->L.Nnoise : 1;
         if (!ok) T.noise[(size_t)slot * d.stride] = 1.0;  // placeholder row; the caller rejects / NaNs the evaluation
     }
+    if (T.bg && !(live && (*u.status == TAMCMC_OK)))  // ... with the matching background series (constant 1)
+        for (int t = tid; t < T.ntiles; t += nt) {
+            double *dst = T.bg + ((size_t)slot * T.ntiles + t) * bg::NH;
+            for (int k = 0; k < bg::NH; k++) dst[k] = (k == 0) ? 1.0 : 0.0;
+        }
 }
 
 }  // namespace tamcmc

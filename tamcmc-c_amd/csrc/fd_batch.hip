@@ -279,6 +279,11 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
         a.B = B;
         a.mults = fa.T.mults; a.offsets = fa.T.pairs; a.noise = fa.T.noise; a.nharvey = fa.T.nh; a.nnoise = fa.T.nn;
         a.partials = c->d_part.p;
+        if (c->precision == TAMCMC_PRECISION_FAST) {
+            HIPCHK(c, c->d_bg.reserve((size_t)B * ntiles * 8));
+            HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, c->d_bg.p, st));
+            a.bg_poly = c->d_bg.p;
+        }
         HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, false, st));
         HIPCHK(c, launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
     } else {
@@ -287,11 +292,16 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
         a.B = C;
         a.mults = fa.T.mults; a.offsets = fa.Bs.pairs; a.noise = fa.Bs.noise; a.nharvey = fa.Bs.nh; a.nnoise = fa.Bs.nn;
         a.partials = c->d_part.p; a.model = c->d_model.p;
+        if (c->precision == TAMCMC_PRECISION_FAST) {
+            HIPCHK(c, c->d_bg.reserve((size_t)C * ntiles * 8));
+            HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, c->d_bg.p, st));
+            a.bg_poly = c->d_bg.p;
+        }
         HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, true, st));
         HIPCHK(c, launch_finalize(c->d_part.p, C, ntiles, c->d_S.p, st));
         // (2) the C*Nvars perturbed points: log-likelihood DIFFERENCES from the delta tables
         LoglikeArgs d = a;
-        d.B = B; d.model = nullptr;
+        d.B = B; d.model = nullptr; d.bg_poly = nullptr;
         d.mults = fa.D.mults; d.offsets = fa.D.pairs; d.noise = fa.D.noise; d.nharvey = fa.D.nh; d.nnoise = fa.D.nn;
         d.partials = c->d_part.p + (size_t)C * ntiles * 2;
         d.d_range = fa.d_range; d.d_flags = fa.d_flags; d.d_row = fa.d_row; d.d_noise_old = fa.d_noise_old; d.model0 = c->d_model.p;

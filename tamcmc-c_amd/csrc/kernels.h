@@ -27,6 +27,9 @@ struct LoglikeArgs {
     double *partials;               // [B x ntiles x 2]
     double *model;                  // [B x Nx] or nullptr
     long *dbg = nullptr;            // optional phase stamps of one workgroup (TAMCMC_DEBUG_STAMPS)
+    // FAST far field: [B x ntiles x 8] background series per (evaluation, tile) built with the table (bg_series.h);
+    // nullptr -> every tile's workgroup computes its own (same arithmetic, same result)
+    const double *bg_poly = nullptr;
     // DELTA launches (windowed finite differences, fd_batch.hip): evaluation b's table holds the CHANGED multiplets only,
     // new rows with +H*V and old rows with -H*V, so the kernel accumulates dM = M(theta + h e_k) - M(theta); the partial
     // sums are those of the log-likelihood DIFFERENCE against the base model row, over the affected bins only.
@@ -57,6 +60,8 @@ bool delta_geometry(int wgs, int K);  // geometries the DELTA variant is instant
 hipError_t launch_loglike(LoglikeArgs a, int mode, int wgs, int K, bool write_model, hipStream_t st);
 // DELTA variant (FAST modes only): a.d_* / a.model0 must be set
 hipError_t launch_loglike_delta(LoglikeArgs a, int mode, int wgs, int K, hipStream_t st);
+// fills bg[B x ntiles x 8] for launch_loglike(a with a.bg_poly = bg, FAST mode, same wgs/K): one thread per (evaluation, tile)
+hipError_t launch_bg_poly(const LoglikeArgs &a, int wgs, int K, double *bg, hipStream_t st);
 hipError_t launch_finalize(const double *partials, int B, int ntiles, double *S, hipStream_t st);
 
 }  // namespace tamcmc

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "bg_series.h"
 
 namespace tamcmc {
 
@@ -50,8 +51,7 @@ constexpr int NC = 16;
 constexpr double RHO_MAX2 = 1.0 / 36.0;  // rho <= 1/6 -> truncation <= 6^-16/(1-1/6) = 4e-13 of the far term (itself <~ 0.3 M)
 constexpr double RHO_MAX2_ASYM = 1.0 / 64.0;  // asymmetric profiles: the far wing can dominate M and the quadratic
                                               // factor feeds degree >= NC terms back -> rho <= 1/8 (3.6e-15)
-constexpr int NH = 8;                    // Taylor coefficients of a Harvey term on a tile (x_c >> h)
-constexpr double EPS_MAX = 0.02;         // ... used when h/x_c <= EPS_MAX: truncation ~ C(p,8) 0.02^8 = 2.6e-14
+constexpr int NH = bg::NH;               // Taylor coefficients of the background on a tile (bg_series.h)
 constexpr int ROW = NC + 2;  // LDS row stride of the coefficient reduction (16-byte aligned, conflict-free b128 writes)
 
 // LDS image of a multiplet (160 B, every field group 16-byte aligned for ds_read_b128).
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     LdsMult *s_m = (LdsMult *)s_buf;
     double *s_rows = (double *)s_buf;
     __shared__ int s_n, s_nfar, s_anyfar;
-    __shared__ int s_far[CHUNK];          // FARFIELD: positions (in s_m) of this chunk's far multiplets
+    __shared__ unsigned short s_slot[CHUNK * 7];  // FARFIELD: this chunk's far COMPONENTS, packed: (position in s_m) << 3 | m
     __shared__ double s_coef[NC];         // FARFIELD: the tile's far-field polynomial
     __shared__ double s_part[WGS / 16][NC];
     __shared__ double s_red[2 * (WGS / 64)];
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     const double xc = a.x0 + ((double)t0 + 0.5 * (double)TILE - 0.5) * a.step;
     // FARFIELD: the background H/(1+(a x)^p) + N0 is analytic on the tile with its singularities ~x_c away, so it joins the
     // tile polynomial: u(s) = (a x_c)^p (1+eps s)^p (binomial series), then the reciprocal series of 1+u.
-    const bool harvey_poly = FARFIELD && bg && (fabs(h) <= EPS_MAX * fabs(xc)) && (xc > 0.0);
+    const bool harvey_poly = FARFIELD && bg && bg::series_valid(xc, h);
     __shared__ double s_lto[TAMCMC_MAX_HARVEY];  // DELTA: ln(1e-3*tau_k) of the base point
     if (FAST && bg && !harvey_poly) {
         if (tid < nh) {
@@ -313,29 +313,16 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
 #pragma unroll
             for (int k = 0; k < NH; k++) f[k] = 0.0;
             const bool lane_new = (hl >= 0 && hl < nh), lane_old = DELTA && (hl >= 32 && hl < 32 + nh);
-            if (lane_new || lane_old) {
+            if (!DELTA && a.bg_poly) {
+                // the table builder already summed the series of this (evaluation, tile): bg_series.h, same arithmetic
+                if (hl >= 0 && hl < NH) s_coef[hl] = a.bg_poly[((size_t)b * a.ntiles + tile) * NH + hl];
+            } else if (lane_new || lane_old) {
                 const double *nq = lane_new ? nz : nzo;
                 const int ht = lane_new ? hl : hl - 32;
-                const double Hh = lane_new ? nq[3 * ht] : -nq[3 * ht], tau = nq[3 * ht + 1], pw = nq[3 * ht + 2];
-                if (tau != 0.0) {
-                    const double eps = h / xc;
-                    double u[NH];
-                    u[0] = exp(pw * log(1e-3 * tau * xc));
-#pragma unroll
-                    for (int k = 0; k < NH - 1; k++) u[k + 1] = u[k] * eps * (pw - (double)k) * (1.0 / (double)(k + 1));
-                    const double iv0 = rcp_nr2(1.0 + u[0]);
-                    f[0] = Hh * iv0;
-#pragma unroll
-                    for (int k = 1; k < NH; k++) {
-                        double acc2 = 0.0;
-#pragma unroll
-                        for (int jj = 1; jj <= k; jj++) acc2 = fma(u[jj], f[k - jj], acc2);
-                        f[k] = -acc2 * iv0;
-                    }
-                }
+                bg::harvey_term_series(lane_new ? nq[3 * ht] : -nq[3 * ht], nq[3 * ht + 1], nq[3 * ht + 2], xc, h, f);
             }
             // lanes hl = 0..nh-1 live in ONE wave: sum their series in lane order with shuffles, lane 0 adds the white noise
-            if (hl >= 0 && hl < 64) {
+            if ((DELTA || !a.bg_poly) && hl >= 0 && hl < 64) {
 #pragma unroll
                 for (int k = 0; k < NH; k++) {
                     double v = f[k];
@@ -409,11 +396,20 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                 for (int m = 0; m < 7; m++) d.nh[m] = make_double2(g.nu[m], g.hv[m]);
             }
             if (FARFIELD) {
-                const unsigned long long fmask = __ballot(far);
-                if (far) s_far[__popcll(fmask & ((1ull << tid) - 1ull))] = __popcll(mask & ((1ull << tid) - 1ull));
+                // far components packed densely (no idle lanes for l < 3): offset = components of the far multiplets before this lane
+                const int lv = ov ? g.l : 0;
+                const unsigned long long lt = (1ull << tid) - 1ull;
+                const unsigned long long f0 = __ballot(far && lv == 0), f1 = __ballot(far && lv == 1), f2 = __ballot(far && lv == 2),
+                                         f3 = __ballot(far && lv >= 3);
+                if (far) {
+                    const int off = __popcll(f0 & lt) + 3 * __popcll(f1 & lt) + 5 * __popcll(f2 & lt) + 7 * __popcll(f3 & lt);
+                    const int pos = __popcll(mask & lt);
+                    const int nm = 2 * (lv > 3 ? 3 : lv) + 1;
+                    for (int m = 0; m < nm; m++) s_slot[off + m] = (unsigned short)((pos << 3) | m);
+                }
                 if (tid == 0) {
-                    s_nfar = __popcll(fmask);
-                    if (fmask) s_anyfar = 1;
+                    s_nfar = __popcll(f0) + 3 * __popcll(f1) + 5 * __popcll(f2) + 7 * __popcll(f3);  // far components of the chunk
+                    if (f0 | f1 | f2 | f3) s_anyfar = 1;
                 }
             }
             if (tid == 0) s_n = __popcll(mask);
@@ -438,12 +434,12 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             double fcoef[NC];
 #pragma unroll
             for (int k = 0; k < NC; k++) fcoef[k] = 0.0;
-            const int nslots = s_nfar * 7;
+            const int nslots = s_nfar;
             for (int slot = tid; slot < nslots; slot += WGS) {
-                const int jf = slot / 7, mm = slot - jf * 7;
-                const LdsMult &M = s_m[s_far[jf]];
-                if (mm < 2 * M.l + 1) {
-                    const double2 nhm = M.nh[mm];
+                const int e = s_slot[slot];
+                const LdsMult &M = s_m[e >> 3];
+                {
+                    const double2 nhm = M.nh[e & 7];
                     const double beta = M.g * h;
                     const double A = M.g * (nhm.x - xc);
                     const double inv = rcp_nr2(fma(A, A, 1.0));
@@ -453,8 +449,11 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                     if (!(M.flags & F_ASYM)) {
                         fcoef[0] = fcoef[0] + cm;
                         fcoef[1] = fcoef[1] + cc;
+                        // terms beyond rho^n <= 1e-13 are dropped (q2 = rho^2); the loop length is the wave's longest
+                        const int nt = (q2 > 1.39e-2) ? 16 : (q2 > 6.8e-3) ? 14 : (q2 > 2.5e-3) ? 12 : (q2 > 5.6e-4) ? 10 : (q2 > 4.6e-5) ? 8 : 6;
 #pragma unroll
                         for (int k = 2; k < NC; k++) {
+                            if ((k & 1) == 0 && k >= 6 && !__any(k < nt)) break;  // wave-uniform
                             const double cn = fma(two_req, cc, -q2 * cm);
                             fcoef[k] = fcoef[k] + cn;
                             cm = cc;
@@ -599,6 +598,24 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
 #undef KSTAMP
 }
 
+// Background series of every (evaluation, tile) of a launch: one thread each (bg_series.h).
+__global__ void __launch_bounds__(WG) k_bg_poly(const double *noise, int noise_stride, const int32_t *nharvey, const int32_t *nnoise,
+                                               int B, int ntiles, int tile_bins, double x0, double step, double *out) {
+    const long id = (long)blockIdx.x * WG + threadIdx.x;
+    if (id >= (long)B * ntiles) return;
+    const int b = (int)(id / ntiles), tile = (int)(id - (long)b * ntiles);
+    const int nn = nnoise[b];
+    if (nn <= 0) return;
+    double xc, h;
+    bg::tile_geometry(tile, tile_bins, x0, step, xc, h);
+    if (!bg::series_valid(xc, h)) return;
+    const double *nz = noise + (size_t)b * noise_stride;
+    double o[NH];
+    bg::tile_series([nz](int i) { return nz[i]; }, nharvey[b], nn, xc, h, o);
+#pragma unroll
+    for (int k = 0; k < NH; k++) out[(size_t)id * NH + k] = o[k];
+}
+
 // One workgroup per evaluation: fixed-order sum of the per-tile partials -> S[b] = sum1 + sum2.
 __global__ void __launch_bounds__(WG) k_finalize(const double *partials, int ntiles, double *S) {
     __shared__ double s_red[2 * (WG / 64)];
@@ -681,6 +698,17 @@ hipError_t launch_loglike_delta(LoglikeArgs a, int mode, int wgs, int K, hipStre
     if (a.tile_rot < 0 || a.tile_rot >= a.ntiles) a.tile_rot = 0;
     const bool ok = (mode == M_FAST) ? launch_geom_delta<M_FAST>(a, wgs, K, (int)grid, st) : launch_geom_delta<M_FAST_DIRECT>(a, wgs, K, (int)grid, st);
     if (!ok) return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_bg_poly(const LoglikeArgs &a, int wgs, int K, double *bg, hipStream_t st) {
+    if (a.B <= 0) return hipSuccess;
+    if (!valid_geometry(wgs, K) || !bg) return hipErrorInvalidValue;
+    const int tb = wgs * K;
+    const int ntiles = (a.Nx + tb - 1) / tb;
+    const long n = (long)a.B * ntiles;
+    hipLaunchKernelGGL(k_bg_poly, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, a.noise, a.noise_stride, a.nharvey, a.nnoise, a.B, ntiles, tb,
+                       a.x0, a.step, bg);
     return hipGetLastError();
 }
 
