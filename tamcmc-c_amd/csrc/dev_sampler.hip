@@ -212,13 +212,13 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
     for (int i = tid; i < Np; i += TB) pp[i] = s_params[i];
 
     // ---- log-prior, then params' -> multiplet table written into the likelihood kernel's input block ----
-    const double logPr = wg_log_prior(a.desc, s_params, U, true);
+    const double logPr = wg_log_prior(a.desc, s_params, U, true, dbg, true);
     PSTAMP(4);
     const bool live = (logPr != -INFINITY) && !isnan(logPr);  // model_def.cpp:472,476-480
     TablePtrs T;
     T.mults = a.mults; T.pairs = a.pairs; T.nh = a.nh; T.nn = a.nn; T.noise = a.noise;
     T.bg = a.bg; T.ntiles = a.ntiles; T.tile_bins = a.tile_bins;
-    wg_unpack(a.desc, s_params, U, slot, T, live);
+    wg_unpack(a.desc, s_params, U, slot, T, live, dbg, true);
     if (tid == 0) {
         *logPr_out = logPr;
         *status_out = *U.status;
@@ -1059,8 +1059,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         long h[16];
         DCHK(hipMemcpyAsync(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost, st));
         DCHK(hipStreamSynchronize(st));
-        fprintf(stderr, "[k_iterate stamps us] settle %.2f | rng+matvec %.2f | scatter+prior %.2f | unpack %.2f\n",
-                (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[4] - h[2]) * 0.01, (h[6] - h[4]) * 0.01);
+        fprintf(stderr, "[k_iterate stamps us] settle %.2f | rng+matvec %.2f | scatter+prior %.2f (constraints %.2f) | unpack %.2f (visibilities %.2f, rows %.2f)\n",
+                (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[4] - h[2]) * 0.01, (h[3] - h[2]) * 0.01, (h[6] - h[4]) * 0.01, (h[5] - h[4]) * 0.01,
+                (h[7] - h[5]) * 0.01);
         const long *k = h + 8;
         fprintf(stderr, "[k_loglike stamps us, middle tile] prologue %.2f | staging %.2f | near %.2f | far+reduce %.2f | horner %.2f | epilogue %.2f\n",
                 (k[1] - k[0]) * 0.01, (k[2] - k[1]) * 0.01, (k[3] - k[2]) * 0.01, (k[4] - k[3]) * 0.01, (k[5] - k[4]) * 0.01, (k[6] - k[5]) * 0.01);

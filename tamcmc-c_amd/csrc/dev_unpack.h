@@ -74,11 +74,77 @@ __device__ inline void unpack_begin(const ModelDesc &d, const UnpackLds &u) {
     __syncthreads();
 }
 
+// m-visibilities (function_rot.cpp): one lane per TERM of each Wigner sum d^l_{i,0}(beta), i=0..l, and of the centre
+// elements d^l_{0,0}(-beta); slot layout: for l=1..3, for i=0..l, then the centre (i=0, -beta): terms s=0..l-i (28).
+// Each lane first FINDS its (l, i, s), then all lanes evaluate their term together (no divergent calls).
+// `lane` = index within the cooperating lanes (>= 28 of them), `sync` = their barrier: __syncthreads() for a whole
+// workgroup, a wavefront fence when ONE wave does the stage beside the others (LDS operations of a wave complete in order).
+template <class Sync>
+__device__ inline void visibilities_stage(const UnpackLds &u, int lane, Sync sync) {
+    mt::Shared *S = u.S;
+    {
+        const double PI = 3.141592653589793238462643;
+        const double ang = PI * S->inc / 180.;
+        int sl = 0, my_l = 0, my_i = 0, my_s = 0;
+        double my_b = 0;
+        for (int l = 1; l <= 3; l++)
+            for (int e = 0; e <= l + 1; e++) {
+                const int i = (e <= l) ? e : 0;
+                for (int s = 0; s <= l - i; s++, sl++)
+                    if (sl == lane) { my_l = l; my_i = i; my_s = s; my_b = (e <= l) ? ang : -ang; }
+            }
+        if (my_l > 0 && S->need_ratio[my_l]) u.w[lane] = mt::wigner_term(my_l, my_i, 0, my_b, my_s);
+    }
+    sync();
+    if (lane < 12) {  // one lane per ELEMENT: sum its terms in order, normalise (dmm's tail)
+        int l = 1, e = lane;
+        if (lane >= 3) { l = 2; e = lane - 3; }
+        if (lane >= 7) { l = 3; e = lane - 7; }
+        if (S->need_ratio[l]) {
+            int sl = 0;
+            for (int ll = 1; ll <= l; ll++)
+                for (int ee = 0; ee <= ll + 1; ee++) {
+                    if (ll == l && ee == e) goto found;
+                    sl += ll - ((ee <= ll) ? ee : 0) + 1;
+                }
+        found:
+            const int i = (e <= l) ? e : 0;
+            double sum = 0;
+            for (int s = 0; s <= l - i; s++) sum = sum + u.w[sl + s];
+            u.w[28 + lane] = mt::wigner_finish(l, i, 0, sum);
+        }
+    }
+    sync();
+    if (lane >= 1 && lane <= 3 && S->need_ratio[lane]) {  // mirror, centre overwrite, square (function_rot.cpp:25-41)
+        const int l = lane, base = 28 + (l == 1 ? 0 : (l == 2 ? 3 : 7));
+        double *V = S->ratios[l];
+        for (int i = 0; i <= l; i++) V[l + i] = u.w[base + i];
+        for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * mt::pow_m1(i);
+        V[l] = u.w[base + l + 1] * mt::pow_m1(0);
+        for (int i = 0; i <= 2 * l; i++) V[i] = V[i] * V[i];
+    }
+    sync();
+}
+struct WgSync { __device__ void operator()() const { __syncthreads(); } };
+struct WaveSync {
+    __device__ void operator()() const {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 // log-prior of the parameter vector in LDS (call_prior, model_def.cpp:421-464): returns the same value in every lane.
 // While the additive terms are summed, the LAST lane prepares the unpack's shared scalars (different wave: overlaps).
-__device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, bool prepare_unpack) {
-    const int tid = threadIdx.x, nt = blockDim.x, Np = d.Np;
-    {
+// vis_in_prior: the LAST wave leaves the prior to the others and prepares the whole unpack instead (shared scalars AND the
+// m-visibilities): pass vis_done = true to wg_unpack afterwards.
+__device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, bool prepare_unpack, long *dbg = nullptr,
+                                      bool vis_in_prior = false) {
+    const int Np = d.Np;
+    const bool split = vis_in_prior && prepare_unpack && blockDim.x >= 128 && (blockDim.x & 63) == 0;
+    const int tid = threadIdx.x, nt = split ? (int)blockDim.x - 64 : (int)blockDim.x;  // nt = lanes working on the prior
+    if (tid >= nt) {  // wave-uniform: the helper wave, part 1 (beside the hard constraints)
+        if (tid == nt) mt::shared_scalars_base(d.model_id, s_params, d.plength, *u.S);
+    } else {
         int st = TAMCMC_OK;
         mt::xreal c = 0;
         if (d.prior_class == 2) {
@@ -98,15 +164,18 @@ __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params
         if (st != TAMCMC_OK) *u.status = st;
     }
     __syncthreads();
+    if (dbg && threadIdx.x == 0) dbg[3] = (long)wall_clock64();
     const int n_extra = (d.prior_class == 2) ? pr::ms_global_extra_terms(d.plength, d.extra) : 0;
     double f = 0;
     int st = TAMCMC_OK;
-    for (int t = tid; t < Np + n_extra; t += nt) {
-        if (t < Np) f = f + pr::generic_prior_term(s_params, Np, d.priors, d.priors_switch, t, &st);
-        else f = f + pr::ms_global_extra_term(s_params, d.plength, d.extra, *u.dnu, t - Np);
-    }
+    if (tid >= nt) visibilities_stage(u, tid - nt, WaveSync());  // helper wave, part 2 (beside the additive terms)
+    else
+        for (int t = tid; t < Np + n_extra; t += nt) {
+            if (t < Np) f = f + pr::generic_prior_term(s_params, Np, d.priors, d.priors_switch, t, &st);
+            else f = f + pr::ms_global_extra_term(s_params, d.plength, d.extra, *u.dnu, t - Np);
+        }
     if (st != TAMCMC_OK) *u.status = st;
-    if (prepare_unpack && tid == nt - 1) mt::shared_scalars_base(d.model_id, s_params, d.plength, *u.S);
+    if (prepare_unpack && !split && tid == nt - 1) mt::shared_scalars_base(d.model_id, s_params, d.plength, *u.S);
     f = wg_sum(f, u.red);
     return *u.reject ? -INFINITY : f;
 }
@@ -114,60 +183,18 @@ __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params
 // params (LDS) -> table rows of evaluation slot `slot` (+ noise row, range, counts).  `live` = the prior is finite
 // (model_def.cpp:472,476-480 skips the model otherwise).  u.S must hold shared_scalars_base (wg_log_prior did it).
 __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, const UnpackLds &u, int slot, const TablePtrs &T,
-                                 bool live) {
+                                 bool live, long *dbg = nullptr, bool vis_done = false) {
     const int tid = threadIdx.x, nt = blockDim.x, per = d.per;
     mt::Shared *S = u.S;
     if (live) {
-        // m-visibilities (function_rot.cpp): one lane per TERM of each Wigner sum d^l_{i,0}(beta), i=0..l, and of the centre
-        // elements d^l_{0,0}(-beta); slot layout: for l=1..3, for i=0..l, then the centre (i=0, -beta): terms s=0..l-i (28).
-        // Each lane first FINDS its (l, i, s), then all lanes evaluate their term together (no divergent calls).
-        {
-            const double PI = 3.141592653589793238462643;
-            const double ang = PI * S->inc / 180.;
-            int sl = 0, my_l = 0, my_i = 0, my_s = 0;
-            double my_b = 0;
-            for (int l = 1; l <= 3; l++)
-                for (int e = 0; e <= l + 1; e++) {
-                    const int i = (e <= l) ? e : 0;
-                    for (int s = 0; s <= l - i; s++, sl++)
-                        if (sl == tid) { my_l = l; my_i = i; my_s = s; my_b = (e <= l) ? ang : -ang; }
-                }
-            if (my_l > 0 && S->need_ratio[my_l]) u.w[tid] = mt::wigner_term(my_l, my_i, 0, my_b, my_s);
-        }
-        __syncthreads();
-        if (tid < 12) {  // one lane per ELEMENT: sum its terms in order, normalise (dmm's tail)
-            int l = 1, e = tid;
-            if (tid >= 3) { l = 2; e = tid - 3; }
-            if (tid >= 7) { l = 3; e = tid - 7; }
-            if (S->need_ratio[l]) {
-                int sl = 0;
-                for (int ll = 1; ll <= l; ll++)
-                    for (int ee = 0; ee <= ll + 1; ee++) {
-                        if (ll == l && ee == e) goto found;
-                        sl += ll - ((ee <= ll) ? ee : 0) + 1;
-                    }
-            found:
-                const int i = (e <= l) ? e : 0;
-                double sum = 0;
-                for (int s = 0; s <= l - i; s++) sum = sum + u.w[sl + s];
-                u.w[28 + tid] = mt::wigner_finish(l, i, 0, sum);
-            }
-        }
-        __syncthreads();
-        if (tid >= 1 && tid <= 3 && S->need_ratio[tid]) {  // mirror, centre overwrite, square (function_rot.cpp:25-41)
-            const int l = tid, base = 28 + (l == 1 ? 0 : (l == 2 ? 3 : 7));
-            double *V = S->ratios[l];
-            for (int i = 0; i <= l; i++) V[l + i] = u.w[base + i];
-            for (int i = -l; i <= 0; i++) V[l + i] = V[l - i] * mt::pow_m1(i);
-            V[l] = u.w[base + l + 1] * mt::pow_m1(0);
-            for (int i = 0; i <= 2 * l; i++) V[i] = V[i] * V[i];
-        }
-        __syncthreads();
+        if (!vis_done) visibilities_stage(u, tid, WgSync());  // workgroup-uniform
+        if (dbg && threadIdx.x == 0) dbg[5] = (long)wall_clock64();
         for (int idx = tid; idx < per; idx += nt) {  // rows go straight to the likelihood kernel's table
             const int st = mt::build_multiplet(d.model_id, *u.poly, s_params, *S, idx, d.x_first, d.x_last, d.Nx, d.step,
                                                &T.mults[(size_t)slot * per + idx]);
             if (st) *u.status = st;
         }
+        if (dbg && threadIdx.x == 0) dbg[7] = (long)wall_clock64();
         for (int i = tid; i < S->L.Nnoise; i += nt) T.noise[(size_t)slot * d.stride + i] = fabs(s_params[S->L.o_noise + i]);
         if (T.bg) {
             // background series of every tile (bg_series.h): the lanes beyond the first wave, which builds the multiplets
