@@ -222,4 +222,5 @@ class HipContext:
 
 
 from . import sampler  # noqa: E402,F401  (registers the tamcmc_sampler_* symbols in EXTRA_ABI)
+from . import inputs  # noqa: E402,F401  (include/tamcmc_io.h)
 from .sampler import Sampler  # noqa: E402,F401

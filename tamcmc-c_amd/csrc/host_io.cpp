@@ -1,0 +1,532 @@
+// host_io.cpp -- input front end of the LOCAL fit (include/tamcmc_io.h): `.data` reader, `.model` reader and the
+// parameter-vector / prior-table builder of model_MS_local_basic.  Plain C++ (no device code).
+//
+// Restates, in its own structure (a table of parameter blocks instead of the reference's per-degree vectors):
+//   Config::read_data_ascii_Ncols  tamcmc/sources/config.cpp:907-1060     Config::setup range cut  config.cpp:312-347
+//   read_MCMC_file_local           tamcmc/sources/io_local.cpp:25-327      build_init_local         io_local.cpp:329-1176
+//   set_noise_params_local         io_local.cpp:1178-1238                  IO_models::fill_param*   io_models.cpp:40-120
+// The reference exits on malformed input; every such exit is a TAMCMC_IO_ERR_* code here.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/tamcmc_hip.h"
+#include "../../include/tamcmc_io.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+std::string trim(const std::string &s) {
+    const char *ws = " \t\r\n";
+    const size_t a = s.find_first_not_of(ws);
+    if (a == std::string::npos) return "";
+    const size_t b = s.find_last_not_of(ws);
+    return s.substr(a, b - a + 1);
+}
+std::vector<std::string> split(const std::string &s, const char *delims) {
+    std::vector<std::string> out;
+    size_t i = 0;
+    while (i < s.size()) {
+        const size_t a = s.find_first_not_of(delims, i);
+        if (a == std::string::npos) break;
+        size_t b = s.find_first_of(delims, a);
+        if (b == std::string::npos) b = s.size();
+        out.push_back(s.substr(a, b - a));
+        i = b;
+    }
+    return out;
+}
+// the reference converts through `istringstream >> long double` (config.cpp:1017) / stod-like helpers
+bool to_double(const std::string &w, double *v) {
+    std::istringstream is(w);
+    long double t = 0;
+    if (!(is >> t)) return false;
+    *v = (double)t;
+    return true;
+}
+bool to_flag(const std::string &w) {  // str_to_bool, string_handler.cpp:481-487
+    std::istringstream is(trim(w));
+    bool b = false;
+    is >> b;
+    return b;
+}
+
+// ---------------------------------------------------------------- parameter blocks (Input_Data of data.h:51-62)
+struct Block {
+    std::vector<std::string> names, prior_names;
+    std::vector<double> inputs;
+    std::vector<int> relax;
+    std::vector<double> priors;  // 4 x n, row-major
+    int n = 0;
+    void init(int size) {  // IO_models::initialise_param, io_models.cpp:255-290
+        n = size;
+        names.assign((size_t)size, "Empty");
+        prior_names.assign((size_t)size, "Fix");
+        inputs.assign((size_t)size, 0.0);
+        relax.assign((size_t)size, 0);
+        priors.assign((size_t)4 * size, -9999.0);
+    }
+    double &pr(int k, int i) { return priors[(size_t)k * n + i]; }
+    // IO_models::fill_param, io_models.cpp:40-75: vals[k + i0] -> priors(k, pos) unless the prior is "Fix"
+    void fill(const std::string &name, const std::string &prior, double value, const std::vector<double> &vals, int pos, int i0) {
+        names[(size_t)pos] = name;
+        prior_names[(size_t)pos] = prior;
+        inputs[(size_t)pos] = value;
+        const bool fixed = (prior == "Fix");
+        relax[(size_t)pos] = fixed ? 0 : 1;
+        for (int k = 0; k < 4; k++) {
+            const size_t q = (size_t)(k + i0);
+            pr(k, pos) = fixed ? -9999.0 : (q < vals.size() ? vals[q] : -9999.0);
+        }
+    }
+    // IO_models::fill_param_vect, io_models.cpp:77-96
+    void fill_vect(const std::vector<double> &v, const std::vector<int> &rel, const std::string &name, const std::string &prior,
+                   const std::vector<double> &vals, int pos, int i0_free) {
+        for (size_t i = 0; i < v.size(); i++) fill(name, rel[i] ? prior : "Fix", v[i], vals, pos + (int)i, i0_free);
+    }
+    std::vector<double> prior_col(int i) {
+        return {pr(0, i), pr(1, i), pr(2, i), pr(3, i)};
+    }
+};
+
+// Config/default/primepriors_ctrl.list
+int prior_id(const std::string &nm) {
+    static const struct { const char *n; int id; } tab[] = {
+        {"None", 0}, {"Fix", 0}, {"Uniform", 1}, {"Gaussian", 2}, {"multivar_Gaussian", 3}, {"Jeffreys", 4}, {"UG", 5}, {"GU", 6},
+        {"GUG", 7}, {"Uniform_abs", 8}, {"Uniform_cos", 9}, {"Jeffreys_abs", 10}, {"Tabulated", 11}, {"Tabulated_2d", 12}, {"Auto", 13}};
+    for (const auto &e : tab)
+        if (nm == e.n) return e.id;
+    return -1;
+}
+
+// harvey_like on a few points (noise_models.cpp:15-39): sum_k H_k/(1+(1e-3 tau_k x)^p_k) for tau_k != 0, + white noise
+double harvey_at(const std::vector<double> &np, double x) {
+    const int nh = ((int)np.size() - 1) / 3;
+    double m = 0;
+    for (int k = 0; k < nh; k++)
+        if (np[(size_t)3 * k + 1] != 0) m += np[(size_t)3 * k] / (1. + std::pow(1e-3 * np[(size_t)3 * k + 1] * x, np[(size_t)3 * k + 2]));
+    return m + np.back();
+}
+
+struct ModeLine { int l; double f; int rf, rH, rW; };
+struct Common { std::string name, prior; std::vector<double> v; };
+struct ModelFile {
+    std::string id;
+    double dnu = 0, c_l = 0, numax = -9999;
+    double range[2] = {0, 0};
+    bool have_range = false;
+    std::vector<ModeLine> modes;
+    std::vector<std::vector<double>> eigen;     // l, nu, nu_min, nu_max, Gamma, H
+    std::vector<double> noise;                  // 10 values, left-padded with -1
+    std::vector<Common> common;
+};
+
+}  // namespace
+
+struct tamcmc_inputs {
+    Block all;
+    int plength[11];
+    double extra[10];
+    double range[2];
+    double dnu, c_l;
+    int model_id, prior_class;
+    std::string model_name;
+};
+
+namespace {
+
+// read_MCMC_file_local (io_local.cpp:25-327): sections are delimited by COUNTING the lines that start with '#'
+int read_model_local(const char *path, int slice_ind, ModelFile &mf) {
+    std::ifstream f(path);
+    if (!f.is_open()) return fail(TAMCMC_IO_ERR_OPEN, std::string("cannot open ") + path);
+    std::vector<std::string> L;
+    for (std::string ln; std::getline(f, ln);) L.push_back(trim(ln));
+    size_t ip = 0;
+    auto have = [&]() { return ip < L.size(); };
+    int hashes = 0, ranges = 0;
+    // --- header + mode list: up to and including the third '#' line (:55-128)
+    while (hashes < 3 && have()) {
+        const std::string &ln = L[ip++];
+        if (ln.empty()) continue;
+        const char c0 = ln[0], c1 = ln.size() > 1 ? ln[1] : ' ';
+        if (c0 == '#') {
+            if (c1 == 'K') {
+                const auto w = split(ln, "= \t");
+                if (w.size() > 1) mf.id = w[1];
+            }
+            hashes++;
+        } else if (c0 == '!') {
+            const auto w = split(ln, " \t");
+            double v = 0;
+            if (w.size() < 2 || !to_double(w[1], &v)) return fail(TAMCMC_IO_ERR_SYNTAX, "'!' line without a value: " + ln);
+            if (c1 == '!') mf.c_l = v;
+            else if (c1 == 'n') mf.numax = v;
+            else mf.dnu = v;
+        } else if (c0 == '*') {
+            const auto w = split(ln, " \t");
+            if (ranges == slice_ind) {
+                if (w.size() < 3 || !to_double(w[1], &mf.range[0]) || !to_double(w[2], &mf.range[1]))
+                    return fail(TAMCMC_IO_ERR_SYNTAX, "bad '*' range line: " + ln);
+                mf.have_range = true;
+            }
+            ranges++;
+        } else {
+            const auto w = split(ln, " \t");
+            if (w.empty()) continue;
+            if (w[0] != "p" && w[0] != "g" && w[0] != "co") return fail(TAMCMC_IO_ERR_SYNTAX, "mode type must be p, g or co: " + ln);
+            ModeLine m;
+            double lv = 0;
+            if (w.size() < 3 || !to_double(w[1], &lv) || !to_double(w[2], &m.f)) return fail(TAMCMC_IO_ERR_SYNTAX, "bad mode line: " + ln);
+            m.l = (int)lv;
+            m.rf = w.size() >= 4 ? to_flag(w[3]) : 1;  // missing flags default to "free" (:97-113)
+            m.rH = w.size() >= 5 ? to_flag(w[4]) : 1;
+            m.rW = w.size() >= 6 ? to_flag(w[5]) : 1;
+            mf.modes.push_back(m);
+        }
+    }
+    if (!mf.have_range) return fail(TAMCMC_IO_ERR_SYNTAX, "no '*' frequency range for this slice index");
+    if (have()) ip++;  // the reference reads one more line here and drops it (the "# Extra parameters" header, :124 then :143)
+    // --- "hyper priors" (:139-176): numeric lines up to the next '#' line; never used by the local models -> skipped
+    while (hashes < 4 && have()) {
+        const std::string &ln = L[ip++];
+        if (!ln.empty() && ln[0] == '#') hashes++;
+    }
+    // --- eigen table (:182-203): rows of six numbers up to the next '#' line
+    while (hashes < 5 && have()) {
+        const std::string &ln = L[ip++];
+        if (ln.empty()) continue;
+        if (ln[0] == '#') { hashes++; continue; }
+        const auto w = split(ln, " \t");
+        if (w.size() != 6) return fail(TAMCMC_IO_ERR_SYNTAX, "eigen table row must have 6 columns: " + ln);
+        std::vector<double> r(6);
+        for (int k = 0; k < 6; k++)
+            if (!to_double(w[(size_t)k], &r[(size_t)k])) return fail(TAMCMC_IO_ERR_SYNTAX, "eigen table: not a number: " + ln);
+        mf.eigen.push_back(r);
+    }
+    // --- noise parameters (:205-230): up to 10 values, right-aligned, missing ones = -1
+    std::vector<double> nz;
+    while (hashes < 6 && have()) {
+        const std::string &ln = L[ip++];
+        if (ln.empty()) continue;
+        if (ln[0] == '#') { hashes++; continue; }
+        for (const auto &w : split(ln, " \t")) {
+            double v = 0;
+            if (!to_double(w, &v)) return fail(TAMCMC_IO_ERR_SYNTAX, "noise parameters: not a number: " + ln);
+            nz.push_back(v);
+        }
+    }
+    if (nz.size() > 10) return fail(TAMCMC_IO_ERR_SYNTAX, "more than 10 noise parameters");
+    mf.noise.assign(10, -1.0);
+    for (size_t k = 0; k < nz.size(); k++) mf.noise[10 - nz.size() + k] = nz[k];
+    // --- noise information of the previous analysis step (:232-256): not used by set_noise_params_local -> skipped
+    while (hashes < 7 && have()) {
+        const std::string &ln = L[ip++];
+        if (!ln.empty() && ln[0] == '#') hashes++;
+    }
+    // --- controls and priors of the common parameters (:258-287): name, prior keyword, up to 5 numbers
+    while (hashes < 9 && have()) {
+        const std::string &ln = L[ip++];
+        if (ln.empty()) continue;
+        if (ln[0] == '#') { hashes++; continue; }
+        const auto w = split(ln, " \t");
+        if (w.size() < 2) return fail(TAMCMC_IO_ERR_SYNTAX, "common-parameter line needs a name and a prior keyword: " + ln);
+        Common c;
+        c.name = w[0];
+        c.prior = w[1];
+        c.v.assign(5, -9999.0);
+        for (size_t k = 2; k < w.size() && k < 7; k++)
+            if (!to_double(w[k], &c.v[k - 2])) c.v[k - 2] = 0.0;  // a non-numeric field (model_fullname's value is in c.prior)
+        mf.common.push_back(c);
+    }
+    return TAMCMC_IO_OK;
+}
+
+int build_local(const ModelFile &mf, double resol, tamcmc_inputs &out) {
+    const long double pi = 3.141592653589793238L;
+    const double G = 6.667e-8, Dnu_sun = 135.1, R_sun = 6.96342e5, M_sun = 1.98855e30;
+    const double rho_sun = (double)(M_sun * 1e3 / (4 * pi * std::pow(R_sun * 1e5, 3) / 3));
+    const double rho = std::pow(mf.dnu / Dnu_sun, 2.) * rho_sun;
+    const double Hmin = 1, Hmax = 10000;
+    // ---- switches read before anything else (io_local.cpp:381-411)
+    std::string model;
+    int do_amp = 0;
+    for (const auto &c : mf.common) {
+        if (c.name == "model_fullname") model = c.prior;
+        if (c.name == "fit_squareAmplitude_instead_Height") {
+            if (c.prior != "bool") return fail(TAMCMC_IO_ERR_SYNTAX, "fit_squareAmplitude_instead_Height must be 'bool'");
+            do_amp = c.v[0] != 0;
+        }
+    }
+    if (model.empty()) return fail(TAMCMC_IO_ERR_SYNTAX, "the .model file has no model_fullname");
+    if (model != "model_MS_local_basic") return fail(TAMCMC_IO_ERR_UNSUPPORTED, "model not covered by this loader: " + model);
+
+    // ---- per degree: the eigen-table rows of that degree, each matched to ONE mode line within 1e-2 (:416-502), then only
+    //      the modes strictly inside the slice's range (:504-557)
+    std::vector<double> f, h, w, fmin, fmax;
+    std::vector<int> rf, rh, rw;
+    int Nf[4] = {0, 0, 0, 0};
+    int lmax = 0;
+    for (const auto &m : mf.modes) lmax = m.l > lmax ? m.l : lmax;
+    if (lmax > 3) return fail(TAMCMC_IO_ERR_SYNTAX, "degrees above 3 are not supported");
+    for (int el = 0; el <= lmax; el++) {
+        bool listed = false;
+        for (const auto &m : mf.modes) listed = listed || m.l == el;
+        if (!listed) continue;
+        for (const auto &e : mf.eigen) {
+            if ((int)e[0] != el) continue;
+            int match = -1, nmatch = 0;
+            for (size_t k = 0; k < mf.modes.size(); k++)
+                if (mf.modes[k].l == el && mf.modes[k].f > e[1] - 1e-2 && mf.modes[k].f < e[1] + 1e-2) { match = (int)k; nmatch++; }
+            if (nmatch != 1) return fail(TAMCMC_IO_ERR_SYNTAX, "eigen-table frequency without a unique entry in the mode list");
+            if (!(e[1] > mf.range[0] && e[1] < mf.range[1])) continue;
+            f.push_back(e[1]); fmin.push_back(e[2]); fmax.push_back(e[3]); w.push_back(e[4]); h.push_back(e[5]);
+            rf.push_back(mf.modes[(size_t)match].rf); rw.push_back(mf.modes[(size_t)match].rW); rh.push_back(mf.modes[(size_t)match].rH);
+            Nf[el]++;
+        }
+    }
+    const int Ntot = (int)f.size();
+    if (Ntot == 0) return fail(TAMCMC_IO_ERR_EMPTY_RANGE, "no mode inside the slice's frequency range");
+    if (do_amp)  // heights -> squared amplitudes pi*H*W (:569-583)
+        for (int i = 0; i < Ntot; i++) h[(size_t)i] = (double)(pi * w[(size_t)i] * h[(size_t)i]);
+    const std::string hname = do_amp ? "Amplitude_l" : "Height_l";
+
+    Block height, width, freq, snlm, inc, noise;
+    height.init(Ntot); width.init(Ntot); freq.init(Ntot); snlm.init(6); inc.init(1); noise.init(1);
+    // ---- defaults (:586-673): Jeffreys on heights and widths, GUG on frequencies
+    height.fill_vect(h, rh, hname, "Jeffreys", {Hmin, Hmax, -9999., -9999.}, 0, 0);
+    const std::vector<double> wdef = {resol, mf.dnu > 0 ? mf.dnu / 3. : 20., -9999., -9999.};
+    width.fill_vect(w, rw, "Width_l", "Jeffreys", wdef, 0, 0);
+    for (int i = 0; i < Ntot; i++) {
+        const double s = 0.01 * std::fabs(fmax[(size_t)i] - fmin[(size_t)i]);
+        freq.fill("Frequency_l", rf[(size_t)i] ? "GUG" : "Fix", f[(size_t)i], {fmin[(size_t)i], fmax[(size_t)i], s, s}, i, 0);
+    }
+    double extra[4] = {0, 0, 0.2, 0};  // :700-705
+    double trunc_c = -1;
+    bool cosi = false, sini = false;
+    auto no_auto = [&](const Common &c) { return c.prior == "Fix_Auto" ? fail(TAMCMC_IO_ERR_SYNTAX, c.name + " cannot be Fix_Auto") : 0; };
+    // ---- the keywords of "# Controls and priors for common parameters" (:707-969)
+    for (const auto &c : mf.common) {
+        const std::string &n = c.name;
+        if (n == "trunc_c") {
+            if (c.prior != "Fix") return fail(TAMCMC_IO_ERR_SYNTAX, "trunc_c must be 'Fix'");
+            trunc_c = c.v[0];
+        } else if (n == "height" || n == "Height" || n == "amplitude" || n == "Amplitude") {
+            if (c.prior == "Fix_Auto") {  // Jeffreys between input/Y and input*X per mode (:748-802)
+                const bool amp = (n == "amplitude" || n == "Amplitude");
+                for (int i = 0; i < Ntot; i++) {
+                    const double s = amp ? (double)(pi * mf.dnu / 3.) : 1.0;
+                    height.fill(hname, rh[(size_t)i] ? "Jeffreys" : "Fix", h[(size_t)i],
+                                {s * h[(size_t)i] / c.v[0], s * h[(size_t)i] * c.v[1], -9999., -9999.}, i, 0);
+                }
+            } else height.fill_vect(h, rh, hname, c.prior, c.v, 0, 1);
+        } else if (n == "width" || n == "Width") {
+            if (c.prior == "Fix_Auto") width.fill_vect(w, rw, "Width_l", "Jeffreys", wdef, 0, 0);
+            else width.fill_vect(w, rw, "Width_l", c.prior, c.v, 0, 0);  // (i0 = 0 for free widths, :845-852)
+        } else if (n == "splitting_a1" || n == "Splitting_a1") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("Splitting_a1", c.prior, c.v[0], c.v, 0, 1);
+        } else if (n == "asphericity_eta" || n == "Asphericity_eta") {
+            if (c.prior == "Fix_Auto") {  // the centrifugal term, always fixed (:887-905)
+                snlm.names[1] = "Asphericity_eta0";
+                snlm.prior_names[1] = "Fix";
+                snlm.relax[1] = 0;
+                snlm.inputs[1] = (c.v[0] == 1 && mf.dnu > 0) ? 3. / (4. * M_PI * rho * G) : 0.0;
+            } else snlm.fill("Asphericity_eta", c.prior, c.v[0], c.v, 1, 1);
+        } else if (n == "splitting_a3" || n == "Splitting_a3") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("Splitting_a3", c.prior, c.v[0], c.v, 2, 1);
+        } else if (n == "asymetry" || n == "Asymetry") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("Lorentzian_asymetry", c.prior, c.v[0], c.v, 5, 1);
+        } else if (n == "inclination" || n == "Inclination") {
+            if (int rc = no_auto(c)) return rc;
+            inc.fill("Inclination", c.prior, c.v[0] >= 90 ? 89.99999 : c.v[0], c.v, 0, 1);
+        } else if (n == "sqrt(splitting_a1).cosi") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("sqrt(splitting_a1).cosi", c.prior, c.v[0], c.v, 3, 1);
+            cosi = true;
+        } else if (n == "sqrt(splitting_a1).sini") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("sqrt(splitting_a1).sini", c.prior, c.v[0], c.v, 4, 1);
+            sini = true;
+        }
+        // freq_smoothness, Visibility_l*: irrelevant for a local fit (:709-720); model_fullname etc. handled above
+    }
+    if (cosi != sini) return fail(TAMCMC_IO_ERR_SYNTAX, "sqrt(splitting_a1).cosi and .sini must both appear");
+    if (!cosi) {
+        // Splitting_a1 + Inclination given: the model fits sqrt(a1) cos i and sqrt(a1) sin i (:978-1003)
+        const double a1 = snlm.inputs[0], ang = (double)(inc.inputs[0] * pi / 180.);
+        if (inc.prior_names[0] == "Fix" && snlm.prior_names[0] == "Fix") {
+            snlm.fill("sqrt(splitting_a1).cosi", "Fix", std::sqrt(a1) * std::cos(ang), snlm.prior_col(0), 3, 0);
+            snlm.fill("sqrt(splitting_a1).sini", "Fix", std::sqrt(a1) * std::sin(ang), snlm.prior_col(0), 4, 0);
+        } else {
+            snlm.pr(1, 0) = std::sqrt(snlm.pr(1, 0));  // upper bound of a1 -> upper bound of sqrt(a1)
+            const std::string p = snlm.prior_names[0];
+            snlm.fill("sqrt(splitting_a1).cosi", p, std::sqrt(a1) * std::cos(ang), snlm.prior_col(0), 3, 0);
+            snlm.fill("sqrt(splitting_a1).sini", p, std::sqrt(a1) * std::sin(ang), snlm.prior_col(0), 4, 0);
+        }
+        if (snlm.inputs[3] < 1e-2) snlm.inputs[3] = 1e-2;
+        if (snlm.inputs[4] < 1e-2) snlm.inputs[4] = 1e-2;
+    }
+    inc.fill("Empty", "Fix", 0, inc.prior_col(0), 0, 1);    // :1004 / :1057
+    snlm.fill("Empty", "Fix", 0, snlm.prior_col(0), 0, 1);  // :1005 / :1059
+    // ---- local white-noise level (set_noise_params_local, :1178-1238): mean of the background at the two ends of the range
+    {
+        std::vector<double> np;
+        for (double v : mf.noise) {
+            if (v == -1) np.push_back(0.0);
+            else if (v >= 0) np.push_back(v);
+        }
+        if (np.size() < 1 || (np.size() - 1) % 3 != 0) return fail(TAMCMC_IO_ERR_SYNTAX, "noise parameters must be 3*Nharvey + 1 values");
+        const double a = harvey_at(np, mf.range[0]), b = harvey_at(np, mf.range[1]);
+        noise.names[0] = "White_Noise_N0";
+        noise.prior_names[0] = "Uniform";
+        noise.relax[0] = 1;
+        noise.inputs[0] = (a + b) / 2.;
+        noise.pr(0, 0) = (a < b ? a : b) * 0.5;
+        noise.pr(1, 0) = (a > b ? a : b) * 1.5;
+    }
+    // ---- assemble (:1067-1118): heights, frequencies, splitting block, widths, noise, inclination, trunc_c, do_amp
+    int *pl = out.plength;
+    pl[0] = Ntot; pl[1] = 0; pl[2] = Nf[0]; pl[3] = Nf[1]; pl[4] = Nf[2]; pl[5] = Nf[3];
+    pl[6] = 6; pl[7] = Ntot; pl[8] = 1; pl[9] = 1; pl[10] = 2;
+    int N = 0;
+    for (int k = 0; k < 11; k++) N += pl[k];
+    Block &A = out.all;
+    A.init(N);
+    auto put = [&](Block &b, int pos) {  // IO_models::add_param, io_models.cpp:122-146
+        for (int i = 0; i < b.n; i++) {
+            A.names[(size_t)(pos + i)] = b.names[(size_t)i];
+            A.prior_names[(size_t)(pos + i)] = b.prior_names[(size_t)i];
+            A.inputs[(size_t)(pos + i)] = b.inputs[(size_t)i];
+            A.relax[(size_t)(pos + i)] = b.relax[(size_t)i];
+            for (int k = 0; k < 4; k++) A.pr(k, pos + i) = b.pr(k, i);
+        }
+    };
+    int p0 = 0;
+    put(height, p0); p0 += pl[0] + pl[1];
+    put(freq, p0); p0 += pl[2] + pl[3] + pl[4] + pl[5];
+    put(snlm, p0); p0 += pl[6];
+    put(width, p0); p0 += pl[7];
+    put(noise, p0); p0 += pl[8];
+    put(inc, p0); p0 += pl[9];
+    A.fill("Truncation parameter", "Fix", trunc_c > 0 ? trunc_c : 10000., {}, p0, 1);  // non-positive c -> full Lorentzian (:1108-1110)
+    A.fill("Switch for fit of Amplitudes or Heights", "Fix", (double)do_amp, {}, p0 + 1, 1);
+    for (int k = 0; k < 10; k++) out.extra[k] = k < 4 ? extra[k] : 0.0;
+    out.range[0] = mf.range[0]; out.range[1] = mf.range[1];
+    out.dnu = mf.dnu; out.c_l = mf.c_l;
+    out.model_id = TAMCMC_MODEL_MS_LOCAL_BASIC;
+    out.prior_class = 3;  // io_local, Config/default/priors_ctrl.list
+    out.model_name = model;
+    for (int i = 0; i < N; i++)
+        if (prior_id(A.prior_names[(size_t)i]) < 0) return fail(TAMCMC_IO_ERR_SYNTAX, "unknown prior keyword: " + A.prior_names[(size_t)i]);
+    return TAMCMC_IO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tamcmc_io_last_error(void) { return g_err.c_str(); }
+
+void tamcmc_io_free(void *p) { std::free(p); }
+
+int tamcmc_io_read_data(const char *path, double **table, int64_t *nrows, int64_t *ncols) {
+    if (!path || !table || !nrows || !ncols) return fail(TAMCMC_IO_ERR_ARG, "null argument");
+    std::ifstream f(path);
+    if (!f.is_open()) return fail(TAMCMC_IO_ERR_OPEN, std::string("cannot open ") + path);
+    std::vector<double> vals;
+    size_t nc = 0, nr = 0;
+    bool header_done = false, labels_seen = false, units_seen = false;
+    for (std::string raw; std::getline(f, raw);) {
+        const std::string ln = trim(raw);
+        if (!header_done) {  // '#' lines, then at most one '!' line, then at most one '*' line (config.cpp:936-1003)
+            if (!ln.empty() && ln[0] == '#' && !labels_seen && !units_seen) continue;
+            if (!ln.empty() && ln[0] == '!' && !labels_seen && !units_seen) { labels_seen = true; continue; }
+            if (!ln.empty() && ln[0] == '*' && !units_seen) { units_seen = true; continue; }
+            header_done = true;
+        }
+        if (ln.empty()) continue;
+        const auto w = split(ln, " \t");
+        if (nr == 0) nc = w.size();
+        for (size_t k = 0; k < nc; k++) {
+            double v = std::nan("");
+            if (k < w.size() && !to_double(w[k], &v)) v = std::nan("");
+            vals.push_back(v);
+        }
+        nr++;
+    }
+    if (nr == 0 || nc == 0) return fail(TAMCMC_IO_ERR_SYNTAX, "no data rows");
+    double *t = (double *)std::malloc(vals.size() * sizeof(double));
+    if (!t) return fail(TAMCMC_IO_ERR_ARG, "out of memory");
+    std::memcpy(t, vals.data(), vals.size() * sizeof(double));
+    *table = t;
+    *nrows = (int64_t)nr;
+    *ncols = (int64_t)nc;
+    return TAMCMC_IO_OK;
+}
+
+int tamcmc_io_select_range(const double *table, int64_t nrows, int64_t ncols, int x_col, double xmin, double xmax, int64_t *imin,
+                           int64_t *imax) {
+    if (!table || !imin || !imax || nrows < 1 || x_col < 0 || x_col >= ncols) return fail(TAMCMC_IO_ERR_ARG, "bad argument");
+    int64_t a = 0;
+    while (a < nrows && table[a * ncols + x_col] < xmin) a++;
+    if (a >= nrows) return fail(TAMCMC_IO_ERR_EMPTY_RANGE, "the requested range starts beyond the data");
+    int64_t b = a;
+    while (b < nrows && table[b * ncols + x_col] < xmax) b++;
+    *imin = a;
+    *imax = b;
+    return TAMCMC_IO_OK;
+}
+
+int tamcmc_io_load_model_local(const char *model_path, int slice_ind, double resol, tamcmc_inputs **out) {
+    if (!model_path || !out || slice_ind < 0) return fail(TAMCMC_IO_ERR_ARG, "bad argument");
+    ModelFile mf;
+    int rc = read_model_local(model_path, slice_ind, mf);
+    if (rc) return rc;
+    tamcmc_inputs *in = new tamcmc_inputs();
+    rc = build_local(mf, resol, *in);
+    if (rc) { delete in; return rc; }
+    *out = in;
+    return TAMCMC_IO_OK;
+}
+
+void tamcmc_inputs_free(tamcmc_inputs *in) { delete in; }
+int tamcmc_inputs_nparams(const tamcmc_inputs *in) { return in ? in->all.n : 0; }
+
+int tamcmc_inputs_get(const tamcmc_inputs *in, double *params, int32_t *relax, double *priors, int32_t *priors_switch, int32_t *plength,
+                      double *extra_priors, double *freq_range, int32_t *model_id, int32_t *prior_class, double *dnu, double *c_l) {
+    if (!in) return fail(TAMCMC_IO_ERR_ARG, "null inputs");
+    const int N = in->all.n;
+    for (int i = 0; i < N; i++) {
+        if (params) params[i] = in->all.inputs[(size_t)i];
+        if (relax) relax[i] = in->all.relax[(size_t)i];
+        if (priors_switch) priors_switch[i] = prior_id(in->all.prior_names[(size_t)i]);
+    }
+    if (priors) std::memcpy(priors, in->all.priors.data(), (size_t)4 * N * sizeof(double));
+    if (plength) for (int k = 0; k < 11; k++) plength[k] = in->plength[k];
+    if (extra_priors) for (int k = 0; k < 10; k++) extra_priors[k] = in->extra[k];
+    if (freq_range) { freq_range[0] = in->range[0]; freq_range[1] = in->range[1]; }
+    if (model_id) *model_id = in->model_id;
+    if (prior_class) *prior_class = in->prior_class;
+    if (dnu) *dnu = in->dnu;
+    if (c_l) *c_l = in->c_l;
+    return TAMCMC_IO_OK;
+}
+const char *tamcmc_inputs_name(const tamcmc_inputs *in, int i) { return (in && i >= 0 && i < in->all.n) ? in->all.names[(size_t)i].c_str() : ""; }
+const char *tamcmc_inputs_prior_name(const tamcmc_inputs *in, int i) {
+    return (in && i >= 0 && i < in->all.n) ? in->all.prior_names[(size_t)i].c_str() : "";
+}
+const char *tamcmc_inputs_model_name(const tamcmc_inputs *in) { return in ? in->model_name.c_str() : ""; }
+
+}  // extern "C"

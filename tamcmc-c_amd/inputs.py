@@ -1,0 +1,105 @@
+"""Input front end (include/tamcmc_io.h): `.data` and local-fit `.model` files -> the `Star` the sampler takes.
+ctypes binding of csrc/host_io.cpp; mirrors Config::read_inputs_priors_local + the data range cut of Config::setup
+(tamcmc/sources/config.cpp:709-723, :312-347 of the reference)."""
+import ctypes as C
+
+import numpy as np
+
+from . import EXTRA_ABI, TamcmcError, lib, _dp, _ip, _vp, _p
+from .synth import Star
+
+_i64p = C.POINTER(C.c_int64)
+
+EXTRA_ABI += [
+    ("tamcmc_io_last_error", C.c_char_p, []),
+    ("tamcmc_io_read_data", C.c_int, [C.c_char_p, C.POINTER(_dp), _i64p, _i64p]),
+    ("tamcmc_io_free", None, [_vp]),
+    ("tamcmc_io_select_range", C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, _i64p, _i64p]),
+    ("tamcmc_io_load_model_local", C.c_int, [C.c_char_p, C.c_int, C.c_double, C.POINTER(_vp)]),
+    ("tamcmc_inputs_free", None, [_vp]),
+    ("tamcmc_inputs_nparams", C.c_int, [_vp]),
+    ("tamcmc_inputs_get", C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip, _dp, _dp, _ip, _ip, _dp, _dp]),
+    ("tamcmc_inputs_name", C.c_char_p, [_vp, C.c_int]),
+    ("tamcmc_inputs_prior_name", C.c_char_p, [_vp, C.c_int]),
+    ("tamcmc_inputs_model_name", C.c_char_p, [_vp]),
+]
+
+
+def _L():
+    L = lib()
+    for name, res, args in EXTRA_ABI:
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise TamcmcError(rc, "%s: %s" % (what, _L().tamcmc_io_last_error().decode()))
+
+
+def read_data(path):
+    """Whole `.data` table as an [nrows, ncols] array (config.cpp:907-1060)."""
+    L = _L()
+    tab = _dp()
+    nr, nc = C.c_int64(0), C.c_int64(0)
+    _check(L.tamcmc_io_read_data(str(path).encode(), C.byref(tab), C.byref(nr), C.byref(nc)), "read_data")
+    try:
+        return np.ctypeslib.as_array(tab, shape=(nr.value, nc.value)).copy()
+    finally:
+        L.tamcmc_io_free(tab)
+
+
+def select_range(table, xmin, xmax, x_col=0):
+    """Row range [imin, imax) the reference keeps for a fit over [xmin, xmax) (config.cpp:312-347)."""
+    L = _L()
+    t = np.ascontiguousarray(table, dtype=np.float64)
+    a, b = C.c_int64(0), C.c_int64(0)
+    _check(L.tamcmc_io_select_range(_p(t), t.shape[0], t.shape[1], int(x_col), float(xmin), float(xmax), C.byref(a), C.byref(b)),
+           "select_range")
+    return a.value, b.value
+
+
+class LocalInputs:
+    """Input_Data of a local fit: params, relax, priors (4 x N), prior ids, plength, extra priors, names."""
+
+    def __init__(self, model_path, slice_ind, resol):
+        L = _L()
+        h = _vp()
+        _check(L.tamcmc_io_load_model_local(str(model_path).encode(), int(slice_ind), float(resol), C.byref(h)), "load_model_local")
+        try:
+            n = L.tamcmc_inputs_nparams(h)
+            self.params = np.zeros(n)
+            self.relax = np.zeros(n, dtype=np.int32)
+            self.priors = np.zeros((4, n))
+            self.priors_switch = np.zeros(n, dtype=np.int32)
+            self.plength = np.zeros(11, dtype=np.int32)
+            self.extra_priors = np.zeros(10)
+            rng = np.zeros(2)
+            mid, pc = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+            dnu, cl = np.zeros(1), np.zeros(1)
+            _check(L.tamcmc_inputs_get(h, _p(self.params), _p(self.relax, _ip), _p(self.priors), _p(self.priors_switch, _ip),
+                                       _p(self.plength, _ip), _p(self.extra_priors), _p(rng), _p(mid, _ip), _p(pc, _ip), _p(dnu),
+                                       _p(cl)), "inputs_get")
+            self.freq_range = (float(rng[0]), float(rng[1]))
+            self.model_id, self.prior_class = int(mid[0]), int(pc[0])
+            self.dnu, self.c_l = float(dnu[0]), float(cl[0])
+            self.names = [L.tamcmc_inputs_name(h, i).decode() for i in range(n)]
+            self.prior_names = [L.tamcmc_inputs_prior_name(h, i).decode() for i in range(n)]
+            self.model_name = L.tamcmc_inputs_model_name(h).decode()
+        finally:
+            L.tamcmc_inputs_free(h)
+
+
+def load_local_star(model_path, data_path, slice_ind=0, x_col=0, y_col=1):
+    """`.model` + `.data` of a local fit -> (Star with x, y cut to the slice's range, LocalInputs)."""
+    tab = read_data(data_path)
+    resol = tab[2, x_col] - tab[1, x_col]  # config.cpp:720
+    inp = LocalInputs(model_path, slice_ind, resol)
+    a, b = select_range(tab, inp.freq_range[0], inp.freq_range[1], x_col)
+    x = np.ascontiguousarray(tab[a:b, x_col])
+    star = Star(inp.model_id, inp.params, inp.plength, x, inp.relax, inp.priors, inp.priors_switch, inp.names, inp.prior_class,
+                inp.extra_priors)
+    star.y = np.ascontiguousarray(tab[a:b, y_col])
+    return star, inp

@@ -109,3 +109,35 @@ def test_device_priors_match_host(pkg, oracle, synth):
         else:
             assert pr0[b] == pytest.approx(want, rel=1e-13, abs=1e-11)
     c.close()
+
+
+def test_c1_from_the_shipped_files(pkg, oracle):
+    """BASELINE config C1 end to end from the reference's own files: `.model` (slice 0) + `.data` -> Input_Data
+    (include/tamcmc_io.h) -> logL parity with the oracle at the file's starting point -> 4 tempered chains on the device."""
+    from tamcmc_c_amd import inputs
+    star, inp = inputs.load_local_star(os.path.join(GOLD, "TF_3443483_local-v3.model"),
+                                       os.path.join(GOLD, "TF_3443483_local-v3_slice1.data"), 0)
+    assert star.x.size == 973 and list(inp.plength) == [2, 0, 1, 0, 1, 0, 6, 2, 1, 1, 2]
+    T = 3.5 ** np.arange(4)
+    P = np.tile(star.params, (4, 1))
+    ref, _, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, star.y, 1.0, T)
+    assert (st_o == 0).all()
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, star.y)
+    got, _, st = ctx.loglike_params_batch(star.model_id, P, star.plength, T)
+    assert (st == 0).all() and np.allclose(got, ref, rtol=1e-11, atol=0)
+    for eng in ("host", "device"):
+        s = pkg.Sampler(ctx, star, nchains=4, lambda_temp=3.5, seed=5, engine=eng, Nt_learn=(20, 400), periods_learn=(1,))
+        st0 = s.state()
+        assert np.isfinite(st0["logPrior"]).all() and np.allclose(st0["logL"], ref, rtol=1e-11)
+        smp, stat = s.run(600, stats=True)
+        st1 = s.state()
+        assert st1["iteration"] == 600 and np.isfinite(stat).all()
+        assert stat[-200:, 0, 2].mean() > st0["logPost"][0] - 5.0        # the cold chain stays in the posterior's bulk
+        lo, hi = star.priors[0, star.index_to_relax], star.priors[1, star.index_to_relax]
+        un = [k for k, i in enumerate(star.index_to_relax) if inp.prior_names[i] == "Uniform"]
+        je = [k for k, i in enumerate(star.index_to_relax) if inp.prior_names[i] == "Jeffreys"]
+        assert np.all(smp[:, 0][:, un] >= lo[un]) and np.all(smp[:, 0][:, un] <= hi[un])   # hard-bounded priors are respected
+        assert np.all(smp[:, 0][:, je] >= 0) and np.all(smp[:, 0][:, je] <= hi[je])       # (modified Jeffreys: support [0, hmax])
+        s.close()
+    ctx.close()

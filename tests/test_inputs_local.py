@@ -1,0 +1,93 @@
+"""Input front end (include/tamcmc_io.h): `.data` reader and the local-fit `.model` loader, checked on
+the reference's own sample input test/inputs/TF_3443483_local-v3.model (committed unchanged under tests/golden/ as a data
+fixture) against values derived by hand from that file with the rules of io_local.cpp / io_models.cpp.
+The reference cannot run here and holds no dump of the resulting Input_Data: parity unpinned beyond these rules."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODEL = os.path.join(GOLD, "TF_3443483_local-v3.model")
+DATA = os.path.join(GOLD, "TF_3443483_local-v3_slice1.data")
+
+
+@pytest.fixture(scope="module")
+def inputs(pkg):
+    from tamcmc_c_amd import inputs as m
+    return m
+
+
+def _harvey(nu):
+    return 664.13440 / (1 + (1e-3 * 32.186165 * nu) ** 4.0) + 355.78922 / (1 + (1e-3 * 13.739317 * nu) ** 2.5) + 5.1845856
+
+
+def test_read_data_and_range_cut(inputs):
+    tab = inputs.read_data(DATA)
+    assert tab.shape == (973, 2)
+    raw = np.array([ln.split() for ln in open(DATA) if ln.strip() and ln.lstrip()[0] not in "#!*"], dtype=np.float64)
+    assert np.array_equal(tab, raw)
+    a, b = inputs.select_range(tab, 95.0, 96.0)
+    assert tab[a, 0] >= 95.0 > tab[a - 1, 0] and tab[b - 1, 0] < 96.0 <= tab[b, 0]
+    assert inputs.select_range(tab, 0.0, 1e9) == (0, 973)
+    with pytest.raises(Exception):
+        inputs.select_range(tab, 1e9, 2e9)       # the reference exits (config.cpp:320-324)
+    with pytest.raises(Exception):
+        inputs.read_data(os.path.join(GOLD, "no_such_file.data"))
+
+
+def test_local_model_slice0(inputs, pkg):
+    resol = 0.00812042
+    inp = inputs.LocalInputs(MODEL, 0, resol)
+    assert inp.model_name == "model_MS_local_basic" and inp.model_id == pkg.MODEL_MS_LOCAL_BASIC and inp.prior_class == 3
+    assert inp.freq_range == (94.30, 102.20) and inp.dnu == 10.6795 and inp.c_l == 2.59256
+    assert list(inp.plength) == [2, 0, 1, 0, 1, 0, 6, 2, 1, 1, 2]          # io_local.cpp:1067-1081
+    assert inp.names == ["Height_l", "Height_l", "Frequency_l", "Frequency_l", "Empty", "Asphericity_eta0", "Splitting_a3",
+                         "sqrt(splitting_a1).cosi", "sqrt(splitting_a1).sini", "Lorentzian_asymetry", "Width_l", "Width_l",
+                         "White_Noise_N0", "Empty", "Truncation parameter", "Switch for fit of Amplitudes or Heights"]
+    # rho = (Dnu/135.1)^2 rho_sun; eta0 = 3/(4 pi rho G)  (io_local.cpp:337-343, :894)
+    rho_sun = 1.98855e30 * 1e3 / (4 * np.pi * (6.96342e5 * 1e5) ** 3 / 3)
+    eta0 = 3.0 / (4.0 * np.pi * (10.6795 / 135.1) ** 2 * rho_sun * 6.667e-8)
+    c45 = np.sqrt(0.4) * np.cos(np.radians(45.0))
+    n0 = 0.5 * (_harvey(94.30) + _harvey(102.20))                            # set_noise_params_local, io_local.cpp:1221-1226
+    want = [1199.06221, 635.50294, 99.10560, 97.77160, 0.0, eta0, 0.0, c45, c45, 0.0, 0.30864, 0.30646, n0, 0.0, 10000.0, 0.0]
+    assert np.allclose(inp.params, want, rtol=1e-13, atol=0)
+    assert list(inp.relax) == [1, 1, 1, 1, 0, 0, 0, 1, 1, 0, 1, 1, 1, 0, 0, 0]
+    assert inp.prior_names == ["Jeffreys", "Jeffreys", "GUG", "GUG", "Fix", "Fix", "Fix", "Uniform", "Uniform", "Fix", "Jeffreys",
+                               "Jeffreys", "Uniform", "Fix", "Fix", "Fix"]
+    assert list(inp.priors_switch) == [4, 4, 7, 7, 0, 0, 0, 1, 1, 0, 4, 4, 1, 0, 0, 0]   # primepriors_ctrl.list
+    P = inp.priors
+    assert np.array_equal(P[:, 0], [1.0, 10000.0, -9999.0, -9999.0])       # "Height Jeffreys 1.0 1 10000": values from the 2nd
+    d0 = 0.01 * abs(99.64391 - 98.76572)
+    assert np.allclose(P[:, 2], [98.76572, 99.64391, d0, d0], rtol=1e-14)   # GUG from the eigen table window
+    d2 = 0.01 * abs(98.67162 - 97.43274)
+    assert np.allclose(P[:, 3], [97.43274, 98.67162, d2, d2], rtol=1e-14)
+    assert np.allclose(P[:, 7], [0.0, np.sqrt(1.5), -9999.0, -9999.0]) and np.array_equal(P[:, 7], P[:, 8])
+    assert np.allclose(P[:, 10], [resol, 10.6795 / 3.0, -9999.0, -9999.0])  # Width Fix_Auto
+    assert np.allclose(P[:, 12, ][:2], [0.5 * min(_harvey(94.30), _harvey(102.20)), 1.5 * max(_harvey(94.30), _harvey(102.20))])
+    assert np.all(P[:, [4, 5, 6, 9, 13, 14, 15]] == -9999.0)                # fixed parameters carry no prior values
+    assert np.allclose(inp.extra_priors[:4], [0, 0, 0.2, 0])
+    # the assembled vector has a finite prior under the local prior class
+    from tamcmc_c_amd import sampler
+    star, _ = inputs.load_local_star(MODEL, DATA, 0)
+    lp, st = sampler.log_prior(star)
+    assert st == 0 and np.isfinite(lp)
+
+
+def test_local_model_other_slices(inputs):
+    s1 = inputs.LocalInputs(MODEL, 1, 0.008)       # 106.65 - 112.74: l=0 109.318, l=2 107.867, l=3 111.445
+    assert list(s1.plength) == [3, 0, 1, 0, 1, 1, 6, 3, 1, 1, 2]
+    assert np.allclose(s1.params[:3], [1563.15512, 828.47217, 95.92497]) and np.allclose(s1.params[3:6], [109.318, 107.867, 111.445])
+    s7 = inputs.LocalInputs(MODEL, 7, 0.008)       # 170.29 - 175.19: l=0 173.685, l=2 172.639
+    assert list(s7.plength[:6]) == [2, 0, 1, 0, 1, 0]
+    with pytest.raises(Exception):
+        inputs.LocalInputs(MODEL, 8, 0.008)        # no ninth '*' range
+    with pytest.raises(Exception):
+        inputs.LocalInputs(os.path.join(GOLD, "missing.model"), 0, 0.008)
+
+
+def test_load_local_star_cuts_the_data(inputs):
+    star, inp = inputs.load_local_star(MODEL, DATA, 0)
+    assert star.x.size == star.y.size == 973                   # the committed slice lies inside [94.30, 102.20)
+    assert star.x[0] >= 94.30 and star.x[-1] < 102.20
+    assert star.nvars == 9 and star.prior_class == 3
