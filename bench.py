@@ -79,9 +79,10 @@ def pmc_traffic():
     """HBM bytes per k_loglike launch from the committed PMC passes (None if no profile has been committed)."""
     p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
-        return json.load(open(p))["hbm_bytes_per_launch"]
+        d = json.load(open(p))
+        return d["hbm_bytes_per_launch"], d.get("launch", "")
     except Exception:
-        return None
+        return None, ""
 
 
 def main():
@@ -170,9 +171,9 @@ def main():
                                   if (a.engine == "device" and a.sampler == "mh") else "host-driven loop"),
                        "arithmetic": a.precision, "component_bin_evals_per_model": W},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(), "traffic_unit": "bytes per launch",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic()[0], "traffic_unit": "bytes per launch",
                          "traffic_source": "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                                           "passes, FETCH_SIZE x2 (gfx950), same 20-evaluation launch; not re-measured live",
+                                           "passes, FETCH_SIZE x2 (gfx950), launch shape: " + pmc_traffic()[1] + "; not re-measured live",
                          "kernel": "k_loglike",
                          "kernel_us_per_launch": k_s * 1e6, "evaluations_per_launch": evals_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,

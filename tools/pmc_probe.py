@@ -1,4 +1,5 @@
-"""Minimal GPU program for rocprofv3 --pmc passes: N launches of the C3 batch (20 chains) through the C ABI."""
+"""Minimal GPU program for rocprofv3 --pmc passes: N launches of a C3 batch through the C ABI.  B = evaluations per launch
+(default 10: the device sampler launches the 20 chains as two chain groups of 10)."""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,7 @@ if K:
     c.set_option(pkg.OPT_BINS_PER_THREAD, K)
 c.set_spectrum(star.x, y)
 rng = np.random.default_rng(0)
-B = 20
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 P = np.tile(star.params, (B, 1)); idx = star.index_to_relax
 P[1:, idx] *= 1 + 0.002 * rng.standard_normal((B - 1, idx.size))
 T = 1.3 ** np.arange(B)

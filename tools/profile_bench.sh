@@ -5,7 +5,7 @@ set -o pipefail
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline --mala-steps 0 > "$OUT/bench_under_rocprof.log" 2>&1
 python3 bench.py --mala-steps 20 2> /dev/null | tail -1 > "$OUT/bench.json"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/pmc_probe.py fast 0 10 > "$OUT/pmc_fetch.log" 2>&1

@@ -25,7 +25,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
             if "k_loglike<1, 64, 8, false" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 if agg:
-    lines += ["## PMC, kernel `k_loglike<FAST, workgroup 64, K=8>` (default geometry), 20-evaluation launch (C3), mean over 10 launches, separate passes", "",
+    lines += ["## PMC, kernel `k_loglike<FAST, workgroup 64, K=8>` (default geometry), 10-evaluation launch (C3: one chain group of the device sampler), mean over 10 launches, separate passes", "",
               "| counter | mean per launch |", "|---|---|"]
     for k in sorted(agg):
         lines.append(f"| {k} | {sum(agg[k])/len(agg[k]):.4g} |")
@@ -34,9 +34,9 @@ if agg:
     if fetch is not None and write is not None:
         hbm = (2.0 * fetch + write) * 1024.0   # FETCH_SIZE/WRITE_SIZE are in KB; gfx950: FETCH_SIZE reads 1/2 of a wide stream
         lines += ["", f"HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB = **{hbm/1e6:.2f} MB** "
-                      f"(algorithmic bytes of the launch: 16 B x 1e5 bins x 20 evaluations = 32 MB; the spectrum is served from L2)."]
+                      f"(algorithmic bytes of the launch: 16 B x 1e5 bins x 10 evaluations = 16 MB; the spectrum is served from L2)."]
         json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write, "correction": "FETCH_SIZE x2 (gfx950)",
-                   "launch": "k_loglike FAST wg=64 K=8, B=20, Nx=1e5"}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+                   "launch": "k_loglike FAST wg=64 K=8, B=10, Nx=1e5", "evaluations": 10}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
 open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(lines) + "\n")
 for f in ks:
     import shutil
