@@ -151,6 +151,24 @@ def main():
                             "alg_GBps": 16.0 * a.nx * mk_e / max(mk_ms * 1e-3, 1e-12) / 1e9}
         ms.close()
 
+    shapes = []
+    if world == 1 and a.sampler == "mh":
+        # the same kernel at other launch sizes (standalone batched calls through the C ABI, live HIP-event timing): the sampler's
+        # launches above are small (one chain group), these show where the kernel goes with more evaluations per launch
+        rng = np.random.default_rng(3)
+        for Bs, reps in ((a.chains, 20), (10 * a.chains, 5)):
+            Pm = np.tile(star.params, (Bs, 1))
+            Pm[1:, star.index_to_relax] *= 1 + 0.002 * rng.standard_normal((Bs - 1, star.nvars))
+            Tm = lam ** (np.arange(Bs) % a.chains)
+            ctx.loglike_params_batch(star.model_id, Pm, star.plength, Tm)
+            ctx.reset_kernel_stats()
+            for _ in range(reps):
+                ctx.loglike_params_batch(star.model_id, Pm, star.plength, Tm)
+            s_ms, s_l, s_e = ctx.kernel_stats()
+            us = s_ms / max(s_l, 1) * 1e3
+            shapes.append({"evaluations_per_launch": Bs, "kernel_us_per_launch": us, "achieved_GBps": 16.0 * a.nx * Bs / (us * 1e-6) / 1e9,
+                           "frac": 16.0 * a.nx * Bs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+
     if rank == 0:
         st_tab, mults, _, _ = pkg.build_mode_table(star.model_id, star.params, star.plength, star.x)
         W = int(((mults["i1"] - mults["i0"]) * (2 * mults["l"] + 1)).sum())
@@ -177,6 +195,10 @@ def main():
                          "kernel": "k_loglike",
                          "kernel_us_per_launch": k_s * 1e6, "evaluations_per_launch": evals_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "launch_note": "the device sampler launches the chains as chain groups on separate streams (TAMCMC_CHAIN_GROUPS, "
+                                        "default 2): each timed launch carries evaluations_per_launch evaluations and overlaps the other "
+                                        "group's proposal kernel",
+                         "other_launch_shapes": shapes,
                          "fp64_valu": {"component_evals_per_s": W * evals_per_launch / k_s,
                                        "note": "the path is fp64-VALU-bound (~110 Lorentzian components per 16 B); FAST mode folds far "
                                                "components into one polynomial per tile, so this is an EFFECTIVE rate"}},

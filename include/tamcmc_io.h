@@ -11,7 +11,8 @@
  *   read_MCMC_file_local                   tamcmc/sources/io_local.cpp:25-327   (.model)
  *   build_init_local + set_noise_params_local   io_local.cpp:329-1238, IO_models io_models.cpp:40-297
  *   Config::convert_priors_names_to_switch config.cpp:725-752 (ids of Config/default/primepriors_ctrl.list)
- * Not covered yet (TAMCMC_IO_ERR_UNSUPPORTED): model_MS_local_Hnlm, the global / asymptotic / ajfit .model dialects.
+ * Not covered yet (TAMCMC_IO_ERR_UNSUPPORTED): model_MS_local_Hnlm, the other global variants (a1n/a1l/a2a3/ajAlm/AppWidth/
+ * Classic_v2,v3), the asymptotic (RGB) and ajfit dialects, the .cfg files.
  * Parity: the reference cannot be run here and ships no expected Input_Data dump: "parity unpinned"; tests pin the
  * result against values derived by hand from the shipped file with the rules cited above.
  */
@@ -46,6 +47,10 @@ typedef struct tamcmc_inputs tamcmc_inputs;
 /* `.model` of a local fit, slice `slice_ind` (0-based '*' range line); resol = x[2]-x[1] of the WHOLE data file
  * (config.cpp:720), used as the lower bound of the automatic width prior. */
 int tamcmc_io_load_model_local(const char *model_path, int slice_ind, double resol, tamcmc_inputs **out);
+/* `.model` of a global main-sequence fit (one '*' range): model_MS_Global_aj_HarveyLike (id 23) and
+ * model_MS_Global_a1etaa3_HarveyLike_Classic (id 3).  Replaces read_MCMC_file_MS_Global + build_init_MS_Global +
+ * set_noise_params (tamcmc/sources/io_ms_global.cpp:27-360, :362-1445, :1447-1536, :1718-1850); prior_class 2. */
+int tamcmc_io_load_model_global(const char *model_path, double resol, tamcmc_inputs **out);
 void tamcmc_inputs_free(tamcmc_inputs *in);
 
 int tamcmc_inputs_nparams(const tamcmc_inputs *in);

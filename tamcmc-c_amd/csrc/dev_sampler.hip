@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "ctx.h"
@@ -710,7 +711,13 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.sp_done, 2 * C)); DCHK(I.dalloc(&a.sp_nprop, 2 * C)); DCHK(I.dalloc(&a.sp_phase, 2 * C));
     DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8));
     a.dbg = nullptr;
-    if (getenv("TAMCMC_DEBUG_STAMPS")) { DCHK(I.dalloc(&a.dbg, 16)); DCHK(hipMemsetAsync(a.dbg, 0, 16 * sizeof(long), st)); }
+    if (const char *es = getenv("TAMCMC_DEBUG_STAMPS")) {
+        // 1: phase stamps of one workgroup per kernel; 2: also a (start, end) pair of EVERY k_loglike workgroup of chain group 0
+        const size_t n = 16 + 8 + 2 * CD * 4096;
+        DCHK(I.dalloc(&a.dbg, n));
+        DCHK(hipMemsetAsync(a.dbg, 0, n * sizeof(long), st));
+        if (atoi(es) == 2) { const long magic = 77; DCHK(hipMemcpyAsync(a.dbg + 8 + 7, &magic, sizeof(long), hipMemcpyHostToDevice, st)); }
+    }
     DCHK(I.dalloc(&a.lz, 2 * C * Nv)); DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, CD * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * CD)); DCHK(I.dalloc(&a.nh, CD)); DCHK(I.dalloc(&a.nn, CD));
     DCHK(I.dalloc(&a.noise, CD * (size_t)a.desc.stride));
@@ -1063,6 +1070,19 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
                 (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[4] - h[2]) * 0.01, (h[3] - h[2]) * 0.01, (h[6] - h[4]) * 0.01, (h[5] - h[4]) * 0.01,
                 (h[7] - h[5]) * 0.01);
         const long *k = h + 8;
+        if (k[7] == 77 && a.ntiles <= 4096) {  // timeline of the last k_loglike launch of chain group 0
+            const int nb = (G > 1 ? goff[1] : a.C), nw = nb * a.ntiles;
+            std::vector<long> w(2 * (size_t)nw);
+            DCHK(hipMemcpy(w.data(), a.dbg + 16, w.size() * sizeof(long), hipMemcpyDeviceToHost));
+            long t0 = w[0], t1 = w[1];
+            for (int q = 0; q < nw; q++) { if (w[2 * q] && w[2 * q] < t0) t0 = w[2 * q]; if (w[2 * q + 1] > t1) t1 = w[2 * q + 1]; }
+            std::vector<double> dur, start;
+            for (int q = 0; q < nw; q++) if (w[2 * q]) { dur.push_back((w[2 * q + 1] - w[2 * q]) * 0.01); start.push_back((w[2 * q] - t0) * 0.01); }
+            std::sort(dur.begin(), dur.end()); std::sort(start.begin(), start.end());
+            auto pct = [](const std::vector<double> &v, double p) { return v.empty() ? 0.0 : v[(size_t)(p * (v.size() - 1))]; };
+            fprintf(stderr, "[k_loglike timeline us] %zu workgroups, first start -> last end %.2f | start p50 %.2f p90 %.2f max %.2f | duration p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+                    dur.size(), (t1 - t0) * 0.01, pct(start, .5), pct(start, .9), pct(start, 1.), pct(dur, .1), pct(dur, .5), pct(dur, .9), pct(dur, 1.));
+        }
         fprintf(stderr, "[k_loglike stamps us, middle tile] prologue %.2f | staging %.2f | near %.2f | far+reduce %.2f | horner %.2f | epilogue %.2f\n",
                 (k[1] - k[0]) * 0.01, (k[2] - k[1]) * 0.01, (k[3] - k[2]) * 0.01, (k[4] - k[3]) * 0.01, (k[5] - k[4]) * 0.01, (k[6] - k[5]) * 0.01);
     }

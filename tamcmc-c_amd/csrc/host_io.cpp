@@ -1,10 +1,13 @@
-// host_io.cpp -- input front end of the LOCAL fit (include/tamcmc_io.h): `.data` reader, `.model` reader and the
-// parameter-vector / prior-table builder of model_MS_local_basic.  Plain C++ (no device code).
+// host_io.cpp -- input front end (include/tamcmc_io.h): `.data` reader, `.model` reader and the parameter-vector /
+// prior-table builders of the local fit (model_MS_local_basic) and of the global main-sequence fits
+// (model_MS_Global_aj_HarveyLike, model_MS_Global_a1etaa3_HarveyLike_Classic).  Plain C++ (no device code).
 //
 // Restates, in its own structure (a table of parameter blocks instead of the reference's per-degree vectors):
 //   Config::read_data_ascii_Ncols  tamcmc/sources/config.cpp:907-1060     Config::setup range cut  config.cpp:312-347
 //   read_MCMC_file_local           tamcmc/sources/io_local.cpp:25-327      build_init_local         io_local.cpp:329-1176
 //   set_noise_params_local         io_local.cpp:1178-1238                  IO_models::fill_param*   io_models.cpp:40-120
+//   read_MCMC_file_MS_Global / build_init_MS_Global / set_noise_params / settings_aj_splittings
+//                                  tamcmc/sources/io_ms_global.cpp:27-360, :362-1445, :1447-1536, :1718-1850
 // The reference exits on malformed input; every such exit is a TAMCMC_IO_ERR_* code here.
 #include <cmath>
 #include <cstdio>
@@ -128,6 +131,7 @@ struct ModelFile {
     std::vector<ModeLine> modes;
     std::vector<std::vector<double>> eigen;     // l, nu, nu_min, nu_max, Gamma, H
     std::vector<double> noise;                  // 10 values, left-padded with -1
+    std::vector<std::vector<double>> noise_s2;  // 10 rows (value, err-, err+), missing leading rows = -1
     std::vector<Common> common;
 };
 
@@ -145,8 +149,9 @@ struct tamcmc_inputs {
 
 namespace {
 
-// read_MCMC_file_local (io_local.cpp:25-327): sections are delimited by COUNTING the lines that start with '#'
-int read_model_local(const char *path, int slice_ind, ModelFile &mf) {
+// read_MCMC_file_local (io_local.cpp:25-327) and read_MCMC_file_MS_Global (io_ms_global.cpp:27-360; same layout, ONE range):
+// sections are delimited by COUNTING the lines that start with '#'
+int read_model_file(const char *path, int slice_ind /* < 0: global fit, one range */, ModelFile &mf) {
     std::ifstream f(path);
     if (!f.is_open()) return fail(TAMCMC_IO_ERR_OPEN, std::string("cannot open ") + path);
     std::vector<std::string> L;
@@ -174,7 +179,8 @@ int read_model_local(const char *path, int slice_ind, ModelFile &mf) {
             else mf.dnu = v;
         } else if (c0 == '*') {
             const auto w = split(ln, " \t");
-            if (ranges == slice_ind) {
+            if (slice_ind < 0 && ranges > 0) return fail(TAMCMC_IO_ERR_SYNTAX, "a global fit takes ONE '*' frequency range (io_ms_global.cpp:93-104)");
+            if (ranges == (slice_ind < 0 ? 0 : slice_ind)) {
                 if (w.size() < 3 || !to_double(w[1], &mf.range[0]) || !to_double(w[2], &mf.range[1]))
                     return fail(TAMCMC_IO_ERR_SYNTAX, "bad '*' range line: " + ln);
                 mf.have_range = true;
@@ -228,11 +234,21 @@ int read_model_local(const char *path, int slice_ind, ModelFile &mf) {
     if (nz.size() > 10) return fail(TAMCMC_IO_ERR_SYNTAX, "more than 10 noise parameters");
     mf.noise.assign(10, -1.0);
     for (size_t k = 0; k < nz.size(); k++) mf.noise[10 - nz.size() + k] = nz[k];
-    // --- noise information of the previous analysis step (:232-256): not used by set_noise_params_local -> skipped
+    // --- noise information of the previous analysis step (:232-256): rows (value, err-, err+), right-aligned to 10 rows
+    std::vector<std::vector<double>> s2;
     while (hashes < 7 && have()) {
         const std::string &ln = L[ip++];
-        if (!ln.empty() && ln[0] == '#') hashes++;
+        if (ln.empty()) continue;
+        if (ln[0] == '#') { hashes++; continue; }
+        const auto w = split(ln, " \t");
+        std::vector<double> r(3, 0.0);
+        for (size_t k = 0; k < 3 && k < w.size(); k++)
+            if (!to_double(w[k], &r[k])) return fail(TAMCMC_IO_ERR_SYNTAX, "noise information: not a number: " + ln);
+        s2.push_back(r);
     }
+    if (s2.size() > 10) return fail(TAMCMC_IO_ERR_SYNTAX, "more than 10 rows of noise information");
+    mf.noise_s2.assign(10, std::vector<double>(3, -1.0));
+    for (size_t k = 0; k < s2.size(); k++) mf.noise_s2[10 - s2.size() + k] = s2[k];
     // --- controls and priors of the common parameters (:258-287): name, prior keyword, up to 5 numbers
     while (hashes < 9 && have()) {
         const std::string &ln = L[ip++];
@@ -433,6 +449,200 @@ int build_local(const ModelFile &mf, double resol, tamcmc_inputs &out) {
     return TAMCMC_IO_OK;
 }
 
+// build_init_MS_Global (io_ms_global.cpp:362-1445) for model_MS_Global_aj_HarveyLike and
+// model_MS_Global_a1etaa3_HarveyLike_Classic, + set_noise_params (:1447-1536)
+int build_global(const ModelFile &mf, double resol, tamcmc_inputs &out) {
+    const long double pi = 3.141592653589793238L;
+    const double Hmin = 1, Hmax = 10000;
+    std::string model;
+    int do_amp = 0;
+    for (const auto &c : mf.common) {
+        if (c.name == "model_fullname") model = c.prior;
+        if (c.name == "fit_squareAmplitude_instead_Height") {
+            if (c.prior != "bool") return fail(TAMCMC_IO_ERR_SYNTAX, "fit_squareAmplitude_instead_Height must be 'bool'");
+            do_amp = c.v[0] != 0;
+        }
+    }
+    if (model.empty()) return fail(TAMCMC_IO_ERR_SYNTAX, "the .model file has no model_fullname");
+    const bool aj = (model == "model_MS_Global_aj_HarveyLike"), classic = (model == "model_MS_Global_a1etaa3_HarveyLike_Classic");
+    if (!aj && !classic) return fail(TAMCMC_IO_ERR_UNSUPPORTED, "model not covered by this loader: " + model);
+    double extra[10] = {1, 2., 1e6, 0.50, 0.20, 0.15, 0.05, 0.05, 0, -1};  // :403-413
+    if (aj) extra[9] = 9;                                                    // :494-499
+    int lmax = 0;
+    for (const auto &m : mf.modes) lmax = m.l > lmax ? m.l : lmax;
+    if (lmax > 3) return fail(TAMCMC_IO_ERR_SYNTAX, "degrees above 3 are not supported");
+    // ---- frequencies of every degree, heights and widths of l=0 only (:530-580)
+    std::vector<double> f, fmin, fmax, h, w;
+    std::vector<int> rf, rh, rw;
+    int Nf[4] = {0, 0, 0, 0};
+    for (int el = 0; el <= lmax; el++)
+        for (const auto &e : mf.eigen) {
+            if ((int)e[0] != el) continue;
+            int match = -1, nmatch = 0;
+            for (size_t k = 0; k < mf.modes.size(); k++)
+                if (mf.modes[k].l == el && mf.modes[k].f > e[1] - 1e-2 && mf.modes[k].f < e[1] + 1e-2) { match = (int)k; nmatch++; }
+            if (nmatch != 1) return fail(TAMCMC_IO_ERR_SYNTAX, "eigen-table frequency without a unique entry in the mode list");
+            f.push_back(e[1]); fmin.push_back(e[2]); fmax.push_back(e[3]);
+            rf.push_back(mf.modes[(size_t)match].rf);
+            if (el == 0) {
+                w.push_back(e[4]); h.push_back(e[5]);
+                rw.push_back(mf.modes[(size_t)match].rW); rh.push_back(mf.modes[(size_t)match].rH);
+            }
+            Nf[el]++;
+        }
+    const int Nh = (int)h.size(), Nfreq = (int)f.size();
+    if (Nh == 0) return fail(TAMCMC_IO_ERR_EMPTY_RANGE, "no l=0 mode in the eigen table");
+    if (do_amp)
+        for (int i = 0; i < Nh; i++) h[(size_t)i] = (double)(pi * w[(size_t)i] * h[(size_t)i]);
+    const std::string hname = do_amp ? "Amplitude_l0" : "Height_l0";
+    Block height, width, freq, snlm, vis, inc, noise;
+    height.init(Nh); width.init(Nh); freq.init(Nfreq); vis.init(lmax); inc.init(1); noise.init(10);
+    // ---- defaults (:640-677)
+    for (int i = 0; i < Nh; i++) height.fill(hname, rh[(size_t)i] ? "Jeffreys" : "Fix", h[(size_t)i], {Hmin, Hmax, -9999., -9999.}, i, 0);
+    const std::vector<double> wdef = {resol, mf.dnu / 3., -9999., -9999.};
+    auto wval = [&](int i) { return w[(size_t)i] < mf.dnu / 3. ? w[(size_t)i] : mf.dnu / 3.1; };
+    for (int i = 0; i < Nh; i++) width.fill("Width_l0", rw[(size_t)i] ? "Jeffreys" : "Fix", wval(i), wdef, i, 0);
+    for (int i = 0; i < Nfreq; i++)
+        freq.fill("Frequency_l", rf[(size_t)i] ? "GUG" : "Fix", f[(size_t)i], {fmin[(size_t)i], fmax[(size_t)i], 0.01 * mf.dnu, 0.01 * mf.dnu}, i, 0);
+    // ---- splitting block (:700-726): classic 6 slots; aj 12 a-coefficients + eta0 switch + asymmetry
+    snlm.init(aj ? 14 : 6);
+    if (aj) snlm.fill("eta0_switch", "Fix", 0, {}, 12, 0);
+    double trunc_c = -1;
+    bool cosi = false, sini = false;
+    int aj_count = 0;
+    auto no_auto = [&](const Common &c) { return c.prior == "Fix_Auto" ? fail(TAMCMC_IO_ERR_SYNTAX, c.name + " cannot be Fix_Auto") : 0; };
+    static const char *aj_names[12] = {"a1_0", "a1_1", "a2_0", "a2_1", "a3_0", "a3_1", "a4_0", "a4_1", "a5_0", "a5_1", "a6_0", "a6_1"};
+    for (const auto &c : mf.common) {
+        const std::string &n = c.name;
+        if (n == "freq_smoothness" || n == "Freq_smoothness") {
+            if (c.prior != "bool") return fail(TAMCMC_IO_ERR_SYNTAX, "freq_smoothness must be 'bool'");
+            extra[0] = c.v[0];
+            extra[1] = c.v[1];
+        } else if (n == "trunc_c") {
+            if (c.prior == "Fix") trunc_c = c.v[0];
+            else if (!to_double(c.prior, &trunc_c)) return fail(TAMCMC_IO_ERR_SYNTAX, "trunc_c must be 'Fix <value>' (or a bare value)");
+        } else if (n == "Frequency" || n == "frequency") {
+            if (c.prior != "GUG" && c.prior != "Uniform") return fail(TAMCMC_IO_ERR_SYNTAX, "Frequency prior must be GUG or Uniform");
+            for (int i = 0; i < Nfreq; i++) {
+                const std::vector<double> v = (c.prior == "GUG") ? std::vector<double>{fmin[(size_t)i], fmax[(size_t)i], c.v[3], c.v[4]}
+                                                                 : std::vector<double>{fmin[(size_t)i], fmax[(size_t)i], -9999., -9999.};
+                freq.fill("Frequency_l", rf[(size_t)i] ? c.prior : "Fix", f[(size_t)i], v, i, 0);
+            }
+        } else if (n == "height" || n == "Height" || n == "amplitude" || n == "Amplitude") {
+            if (int rc = no_auto(c)) return rc;
+            for (int i = 0; i < Nh; i++) height.fill(hname, rh[(size_t)i] ? c.prior : "Fix", h[(size_t)i], c.v, i, 0);  // values from the FIRST number (:880-886)
+        } else if (n == "width" || n == "Width") {
+            const bool au = (c.prior == "Fix_Auto");
+            for (int i = 0; i < Nh; i++) width.fill("Width_l", rw[(size_t)i] ? (au ? "Jeffreys" : c.prior) : "Fix", wval(i), au ? wdef : c.v, i, 0);
+        } else if (n == "splitting_a1" || n == "Splitting_a1") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("Splitting_a1", c.prior, c.v[0], c.v, 0, 1);
+        } else if (n == "asphericity_eta" || n == "Asphericity_eta") {  // kept as a fixed 0: the model computes eta0 itself (:956-962)
+            snlm.names[1] = "Asphericity_eta";
+            snlm.prior_names[1] = "Fix";
+            snlm.relax[1] = 0;
+            snlm.inputs[1] = 0;
+        } else if (n == "splitting_a3" || n == "Splitting_a3") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("Splitting_a3", c.prior, c.v[0], c.v, 2, 1);
+        } else if (n == "asymetry" || n == "Asymetry") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("Lorentzian_asymetry", c.prior, c.v[0], c.v, aj ? snlm.n - 1 : 5, 1);
+        } else if (n == "visibility_l1" || n == "Visibility_l1" || n == "visibility_l2" || n == "Visibility_l2" || n == "visibility_l3" ||
+                   n == "Visibility_l3") {
+            if (int rc = no_auto(c)) return rc;
+            const int k = n.back() - '0';
+            if (lmax >= k) vis.fill(std::string("Visibility_l") + n.back(), c.prior, c.v[0], c.v, k - 1, 1);
+        } else if (n == "inclination" || n == "Inclination") {
+            if (int rc = no_auto(c)) return rc;
+            inc.fill("Inclination", c.prior, c.v[0] >= 90 ? 89.99999 : c.v[0], c.v, 0, 1);
+        } else if (n == "sqrt(splitting_a1).cosi" || n == "sqrt(splitting_a1).sini") {
+            if (int rc = no_auto(c)) return rc;
+            const bool is_cos = (n == "sqrt(splitting_a1).cosi");
+            snlm.fill(n, c.prior, c.v[0], c.v, is_cos ? 3 : 4, 1);
+            (is_cos ? cosi : sini) = true;
+        } else if (aj) {  // settings_aj_splittings, :1718-1850
+            for (int k = 0; k < 12; k++)
+                if (n == aj_names[k]) {
+                    if (c.prior == "Fix_Auto") return fail(TAMCMC_IO_ERR_SYNTAX, n + " cannot be Fix_Auto");
+                    snlm.fill(n, c.prior, c.v[0], c.v, k, 1);
+                    aj_count++;
+                }
+        }
+    }
+    if (aj && aj_count != 12) return fail(TAMCMC_IO_ERR_SYNTAX, "the aj model needs the 12 keywords a1_0 ... a6_1 (:1178-1181)");
+    if (cosi != sini) return fail(TAMCMC_IO_ERR_SYNTAX, "sqrt(splitting_a1).cosi and .sini must both appear");
+    if (cosi) {
+        if (classic) return fail(TAMCMC_IO_ERR_SYNTAX, "the Classic model takes Splitting_a1 and Inclination (:1289-1294)");
+        inc.fill("Empty", "Fix", 0, inc.prior_col(0), 0, 1);
+        snlm.fill("Empty", "Fix", 0, snlm.prior_col(0), 0, 1);
+    }
+    // ---- noise (set_noise_params, :1447-1536): first two Harvey profiles fixed, the third and the white noise Gaussian
+    {
+        static const char *nn[3] = {"Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p"};
+        for (int k = 0; k < 9; k++) noise.names[(size_t)k] = nn[k % 3];
+        noise.names[9] = "White_Noise_N0";
+        for (int k = 0; k < 10; k++) {
+            noise.inputs[(size_t)k] = mf.noise[(size_t)k];
+            const bool free_k = k >= 6;
+            noise.prior_names[(size_t)k] = free_k ? "Gaussian" : "Fix";
+            noise.relax[(size_t)k] = free_k ? 1 : 0;
+        }
+        for (int g3 = 0; g3 < 3; g3++) {  // an absent / non-positive profile is switched off: (0, 0, 1) fixed
+            const int b = 3 * g3;
+            if (noise.inputs[(size_t)b] <= 0 || noise.inputs[(size_t)b + 1] <= 0 || noise.inputs[(size_t)b + 2] <= 0) {
+                for (int k = 0; k < 3; k++) { noise.prior_names[(size_t)(b + k)] = "Fix"; noise.relax[(size_t)(b + k)] = 0; }
+                noise.inputs[(size_t)b] = 0; noise.inputs[(size_t)b + 1] = 0; noise.inputs[(size_t)b + 2] = 1;
+            }
+        }
+        const auto &S = mf.noise_s2;
+        for (int k = 6; k <= 9; k++) noise.pr(0, k) = S[(size_t)k][0];
+        noise.pr(1, 6) = (S[6][1] + S[6][2]) * 3. / 2;
+        noise.pr(1, 7) = (S[7][1] + S[7][2]) * 3. / 2;
+        noise.pr(1, 8) = (S[8][1] != 0) ? (S[8][1] + S[8][2]) * 3. / 2 : noise.pr(0, 8) * 0.1;
+        noise.pr(1, 9) = noise.pr(0, 9) * 0.1;  // Gaussian white-noise prior
+        const double floor_rel[4] = {0.05, 0.005, 0.05, 0.0005};
+        for (int k = 6; k <= 9; k++)
+            if (noise.pr(1, k) / noise.pr(0, k) <= floor_rel[k - 6] && noise.prior_names[(size_t)k] != "Fix") noise.pr(1, k) = noise.pr(0, k) * floor_rel[k - 6];
+    }
+    // ---- assemble (:1327-1376): heights, visibilities, frequencies, splitting block, widths, noise, inclination, trunc_c, do_amp
+    int *pl = out.plength;
+    pl[0] = Nh; pl[1] = lmax; pl[2] = Nf[0]; pl[3] = Nf[1]; pl[4] = Nf[2]; pl[5] = Nf[3];
+    pl[6] = snlm.n; pl[7] = Nh; pl[8] = 10; pl[9] = 1; pl[10] = 2;
+    int N = 0;
+    for (int k = 0; k < 11; k++) N += pl[k];
+    Block &A = out.all;
+    A.init(N);
+    auto put = [&](Block &b, int pos) {
+        for (int i = 0; i < b.n; i++) {
+            A.names[(size_t)(pos + i)] = b.names[(size_t)i];
+            A.prior_names[(size_t)(pos + i)] = b.prior_names[(size_t)i];
+            A.inputs[(size_t)(pos + i)] = b.inputs[(size_t)i];
+            A.relax[(size_t)(pos + i)] = b.relax[(size_t)i];
+            for (int k = 0; k < 4; k++) A.pr(k, pos + i) = b.pr(k, i);
+        }
+    };
+    int p0 = 0;
+    put(height, p0); p0 += pl[0];
+    put(vis, p0); p0 += pl[1];
+    put(freq, p0); p0 += pl[2] + pl[3] + pl[4] + pl[5];
+    put(snlm, p0); p0 += pl[6];
+    put(width, p0); p0 += pl[7];
+    put(noise, p0); p0 += pl[8];
+    put(inc, p0); p0 += pl[9];
+    A.fill("Truncation parameter", "Fix", trunc_c > 0 ? trunc_c : 10000., {}, p0, 1);
+    A.fill("Switch for fit of Amplitudes or Heights", "Fix", (double)do_amp, {}, p0 + 1, 1);
+    for (int k = 0; k < 10; k++) out.extra[k] = extra[k];
+    out.range[0] = mf.range[0]; out.range[1] = mf.range[1];
+    out.dnu = mf.dnu; out.c_l = mf.c_l;
+    out.model_id = aj ? TAMCMC_MODEL_MS_GLOBAL_AJ : TAMCMC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC;
+    out.prior_class = 2;  // io_MS_Global, Config/default/priors_ctrl.list
+    out.model_name = model;
+    for (int i = 0; i < N; i++)
+        if (prior_id(A.prior_names[(size_t)i]) < 0) return fail(TAMCMC_IO_ERR_SYNTAX, "unknown prior keyword: " + A.prior_names[(size_t)i]);
+    return TAMCMC_IO_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -492,10 +702,22 @@ int tamcmc_io_select_range(const double *table, int64_t nrows, int64_t ncols, in
 int tamcmc_io_load_model_local(const char *model_path, int slice_ind, double resol, tamcmc_inputs **out) {
     if (!model_path || !out || slice_ind < 0) return fail(TAMCMC_IO_ERR_ARG, "bad argument");
     ModelFile mf;
-    int rc = read_model_local(model_path, slice_ind, mf);
+    int rc = read_model_file(model_path, slice_ind, mf);
     if (rc) return rc;
     tamcmc_inputs *in = new tamcmc_inputs();
     rc = build_local(mf, resol, *in);
+    if (rc) { delete in; return rc; }
+    *out = in;
+    return TAMCMC_IO_OK;
+}
+
+int tamcmc_io_load_model_global(const char *model_path, double resol, tamcmc_inputs **out) {
+    if (!model_path || !out) return fail(TAMCMC_IO_ERR_ARG, "bad argument");
+    ModelFile mf;
+    int rc = read_model_file(model_path, -1, mf);
+    if (rc) return rc;
+    tamcmc_inputs *in = new tamcmc_inputs();
+    rc = build_global(mf, resol, *in);
     if (rc) { delete in; return rc; }
     *out = in;
     return TAMCMC_IO_OK;

@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     const int tid = threadIdx.x;
 #define KSTAMP(k) do { if (a.dbg && b == 0 && tile == a.ntiles / 2 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
     KSTAMP(0);
+    const long wg_t0 = (a.dbg && a.dbg[7] == 77) ? (long)wall_clock64() : 0;  // per-workgroup timeline (TAMCMC_DEBUG_STAMPS=2)
     constexpr int TILE = WGS * K;
     const int t0 = tile * TILE;
     const int t1 = min(t0 + TILE, a.Nx);
@@ -271,6 +272,12 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     }
 
     const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
+    // prebuilt background series of this (evaluation, tile): issued now, stored to LDS when the tile polynomial is set up
+    double bg_pre = 0.0;
+    {
+        const int hl0 = (WGS > 64) ? tid - 64 : tid;
+        if (FARFIELD && !DELTA && a.bg_poly && hl0 >= 0 && hl0 < NH) bg_pre = a.bg_poly[((size_t)b * a.ntiles + tile) * NH + hl0];
+    }
     tamcmc_multiplet g;
     double xv[K], yv[K], acc[K];
     int bin[K];
@@ -315,7 +322,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             const bool lane_new = (hl >= 0 && hl < nh), lane_old = DELTA && (hl >= 32 && hl < 32 + nh);
             if (!DELTA && a.bg_poly) {
                 // the table builder already summed the series of this (evaluation, tile): bg_series.h, same arithmetic
-                if (hl >= 0 && hl < NH) s_coef[hl] = a.bg_poly[((size_t)b * a.ntiles + tile) * NH + hl];
+                if (hl >= 0 && hl < NH) s_coef[hl] = bg_pre;
             } else if (lane_new || lane_old) {
                 const double *nq = lane_new ? nz : nzo;
                 const int ht = lane_new ? hl : hl - 32;
@@ -595,6 +602,11 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         p[1] = out[1];
     }
     KSTAMP(6);
+    if (a.dbg && a.dbg[7] == 77 && tid == 0) {
+        long *w = a.dbg + 8 + 2 * ((size_t)b * a.ntiles + tile);
+        w[0] = wg_t0;
+        w[1] = (long)wall_clock64();
+    }
 #undef KSTAMP
 }
 

@@ -16,6 +16,7 @@ EXTRA_ABI += [
     ("tamcmc_io_free", None, [_vp]),
     ("tamcmc_io_select_range", C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, _i64p, _i64p]),
     ("tamcmc_io_load_model_local", C.c_int, [C.c_char_p, C.c_int, C.c_double, C.POINTER(_vp)]),
+    ("tamcmc_io_load_model_global", C.c_int, [C.c_char_p, C.c_double, C.POINTER(_vp)]),
     ("tamcmc_inputs_free", None, [_vp]),
     ("tamcmc_inputs_nparams", C.c_int, [_vp]),
     ("tamcmc_inputs_get", C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip, _dp, _dp, _ip, _ip, _dp, _dp]),
@@ -61,13 +62,12 @@ def select_range(table, xmin, xmax, x_col=0):
     return a.value, b.value
 
 
-class LocalInputs:
-    """Input_Data of a local fit: params, relax, priors (4 x N), prior ids, plength, extra priors, names."""
+class ModelInputs:
+    """Input_Data built from a `.model` file: params, relax, priors (4 x N), prior ids, plength, extra priors, names."""
 
-    def __init__(self, model_path, slice_ind, resol):
+    def __init__(self, handle):
         L = _L()
-        h = _vp()
-        _check(L.tamcmc_io_load_model_local(str(model_path).encode(), int(slice_ind), float(resol), C.byref(h)), "load_model_local")
+        h = handle
         try:
             n = L.tamcmc_inputs_nparams(h)
             self.params = np.zeros(n)
@@ -90,6 +90,39 @@ class LocalInputs:
             self.model_name = L.tamcmc_inputs_model_name(h).decode()
         finally:
             L.tamcmc_inputs_free(h)
+
+
+class LocalInputs(ModelInputs):
+    """Local fit (model_MS_local_basic), slice `slice_ind` of the `.model` file."""
+
+    def __init__(self, model_path, slice_ind, resol):
+        h = _vp()
+        _check(_L().tamcmc_io_load_model_local(str(model_path).encode(), int(slice_ind), float(resol), C.byref(h)), "load_model_local")
+        super().__init__(h)
+
+
+class GlobalInputs(ModelInputs):
+    """Global main-sequence fit (model_MS_Global_aj_HarveyLike, model_MS_Global_a1etaa3_HarveyLike_Classic)."""
+
+    def __init__(self, model_path, resol):
+        h = _vp()
+        _check(_L().tamcmc_io_load_model_global(str(model_path).encode(), float(resol), C.byref(h)), "load_model_global")
+        super().__init__(h)
+
+
+def star_from_inputs(inp, x, y=None):
+    star = Star(inp.model_id, inp.params, inp.plength, x, inp.relax, inp.priors, inp.priors_switch, inp.names, inp.prior_class,
+                inp.extra_priors)
+    star.y = y
+    return star
+
+
+def load_global_star(model_path, data_path, x_col=0, y_col=1):
+    """`.model` + `.data` of a global fit -> (Star with x, y cut to the file's range, GlobalInputs)."""
+    tab = read_data(data_path)
+    inp = GlobalInputs(model_path, tab[2, x_col] - tab[1, x_col])  # config.cpp:682
+    a, b = select_range(tab, inp.freq_range[0], inp.freq_range[1], x_col)
+    return star_from_inputs(inp, np.ascontiguousarray(tab[a:b, x_col]), np.ascontiguousarray(tab[a:b, y_col])), inp
 
 
 def load_local_star(model_path, data_path, slice_ind=0, x_col=0, y_col=1):

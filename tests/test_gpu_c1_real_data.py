@@ -141,3 +141,30 @@ def test_c1_from_the_shipped_files(pkg, oracle):
         assert np.all(smp[:, 0][:, je] >= 0) and np.all(smp[:, 0][:, je] <= hi[je])       # (modified Jeffreys: support [0, hmax])
         s.close()
     ctx.close()
+
+
+def test_global_aj_model_file_on_the_device(pkg, oracle):
+    """The reference's Sun sample `.model` (model_MS_Global_aj_HarveyLike, 90 parameters, 71 free) through the loader; the
+    reference ships no `.data` for it, so the spectrum is the model of the file's starting point times Exp(1) noise."""
+    from tamcmc_c_amd import inputs
+    step = 0.0317
+    x = 2330.0 + step * np.arange(int((3660.0 - 2330.0) / step))
+    inp = inputs.GlobalInputs(os.path.join(GOLD, "Sun_19992002_incfix_fast_Priorevalrange.model"), step)
+    star = inputs.star_from_inputs(inp, x)
+    st_m, m0 = oracle.call_model(star.model_id, star.params, star.plength, x)
+    assert st_m == 0 and np.all(m0 > 0)
+    y = star.set_spectrum_from_model(m0, 3)
+    T = 1.5 ** np.arange(6)
+    P = np.tile(star.params, (6, 1))
+    ref, _, st_o = oracle.loglike_batch(star.model_id, P, star.plength, x, y, 1.0, T)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(x, y)
+    got, _, st = ctx.loglike_params_batch(star.model_id, P, star.plength, T)
+    assert (st == 0).all() and (st_o == 0).all() and np.allclose(got, ref, rtol=1e-11, atol=0)
+    s = pkg.Sampler(ctx, star, nchains=6, lambda_temp=1.5, seed=9, engine="device", Nt_learn=(10, 300), periods_learn=(1,))
+    st0 = s.state()
+    assert np.isfinite(st0["logPrior"]).all() and np.allclose(st0["logL"], ref, rtol=1e-11)
+    smp, stat = s.run(400, stats=True)
+    assert np.isfinite(stat).all() and s.state()["iteration"] == 400
+    assert (smp[:, 0] != smp[0, 0]).any()            # the cold chain moves
+    s.close(); ctx.close()

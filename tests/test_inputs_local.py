@@ -91,3 +91,51 @@ def test_load_local_star_cuts_the_data(inputs):
     assert star.x.size == star.y.size == 973                   # the committed slice lies inside [94.30, 102.20)
     assert star.x[0] >= 94.30 and star.x[-1] < 102.20
     assert star.nvars == 9 and star.prior_class == 3
+
+
+SUN = os.path.join(GOLD, "Sun_19992002_incfix_fast_Priorevalrange.model")   # reference: test/inputs/Sun/fast/ (unchanged copy)
+
+
+def test_global_model_aj(inputs, pkg):
+    """model_MS_Global_aj_HarveyLike from the reference's Sun sample (io_ms_global.cpp rules, hand-derived expectations)."""
+    resol = 0.0105
+    inp = inputs.GlobalInputs(SUN, resol)
+    assert inp.model_name == "model_MS_Global_aj_HarveyLike" and inp.model_id == pkg.MODEL_MS_GLOBAL_AJ and inp.prior_class == 2
+    assert inp.freq_range == (2330.0, 3660.0) and inp.dnu == 135.00258
+    assert list(inp.plength) == [10, 3, 10, 10, 10, 10, 14, 10, 10, 1, 2] and inp.params.size == 90   # io_ms_global.cpp:1313-1324
+    o = np.cumsum([0] + list(inp.plength))
+    # heights / widths: the l=0 rows of the eigen table; "Height Jeffreys 1 1000" -> values from the FIRST number (:880-886)
+    assert np.allclose(inp.params[:3], [0.35844, 0.64263, 1.00745]) and np.array_equal(inp.priors[:, 0], [1.0, 1000.0, -9999.0, -9999.0])
+    assert inp.names[o[1]:o[2]] == ["Visibility_l1", "Visibility_l2", "Visibility_l3"]
+    assert np.allclose(inp.params[o[1]:o[2]], [1.5, 0.53, 0.08]) and np.allclose(inp.priors[:2, o[1] + 1], [0.53, 0.03])
+    f = inp.params[o[2]:o[6]]
+    assert np.isclose(f[0], 2362.80591) and np.isclose(f[10], 2425.59204) and np.isclose(f[39], 3625.77271)
+    k = o[2] + 10                                                          # first l=1 frequency: GUG from its window, sigma = Dnu/100
+    assert inp.prior_names[k] == "GUG" and np.allclose(inp.priors[:, k], [2424.64893, 2426.53516, 1.3500258, 1.3500258])
+    s = o[6]
+    assert inp.names[s:s + 14] == ["a1_0", "a1_1", "a2_0", "a2_1", "a3_0", "a3_1", "a4_0", "a4_1", "a5_0", "a5_1", "a6_0", "a6_1",
+                                    "eta0_switch", "Lorentzian_asymetry"]
+    assert list(inp.relax[s:s + 14]) == [1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1]
+    assert np.allclose(inp.priors[:2, s], [0.1, 0.6]) and inp.params[s] == 0.4 and inp.params[s + 2] == -0.02
+    assert inp.prior_names[s + 13] == "Jeffreys_abs" and np.allclose(inp.priors[:2, s + 13], [5.0, 200.0])
+    wd = o[7]
+    assert inp.names[wd] == "Width_l" and np.allclose(inp.priors[:2, wd], [resol, 135.00258 / 3.0]) and inp.params[wd] == 0.75319
+    nz = o[8]                                                              # set_noise_params, io_ms_global.cpp:1447-1536
+    assert np.allclose(inp.params[nz:nz + 10], [0, 0, 1, 1.2709550, 49.575897, 2.0, 2.6596093, 1.5192964, 2.0, 0.0051731238])
+    assert list(inp.relax[nz:nz + 10]) == [0, 0, 0, 0, 0, 0, 1, 1, 1, 1]
+    assert inp.prior_names[nz + 6:nz + 10] == ["Gaussian"] * 4
+    assert np.allclose(inp.priors[:2, nz + 6], [2.6596093, 2.6596093 * 0.05])          # 3/2 (err- + err+) = 2.4 % -> 5 % floor
+    assert np.allclose(inp.priors[:2, nz + 7], [1.5192964, (0.0074767880 + 0.0075137648) * 1.5])
+    assert np.allclose(inp.priors[:2, nz + 8], [2.0, 0.2])                              # p without errors -> 10 %
+    assert np.allclose(inp.priors[:2, nz + 9], [0.0051731238, 0.00051731238])           # Gaussian N0: 10 %
+    assert inp.names[o[9]] == "Inclination" and inp.params[o[9]] == 88.18647 and inp.relax[o[9]] == 0
+    assert inp.params[o[10]] == 50.0 and inp.params[o[10] + 1] == 0.0                   # trunc_c, do_amp
+    assert np.allclose(inp.extra_priors, [1, 2, 1e6, 0.5, 0.2, 0.15, 0.05, 0.05, 0, 9])
+    from tamcmc_c_amd import sampler
+    star = inputs.star_from_inputs(inp, np.arange(2330.0, 3660.0, resol))
+    lp, st = sampler.log_prior(star)
+    assert st == 0 and np.isfinite(lp) and star.nvars == int(inp.relax.sum()) == 71
+    with pytest.raises(Exception):
+        inputs.GlobalInputs(MODEL, resol)           # eight '*' ranges: not a global-fit file (io_ms_global.cpp:93-104)
+    with pytest.raises(Exception):
+        inputs.LocalInputs(SUN, 0, resol)           # the loaders refuse each other's model_fullname
