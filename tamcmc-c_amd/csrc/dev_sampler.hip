@@ -213,13 +213,14 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
     for (int i = tid; i < Np; i += TB) pp[i] = s_params[i];
 
     // ---- log-prior, then params' -> multiplet table written into the likelihood kernel's input block ----
-    const double logPr = wg_log_prior(a.desc, s_params, U, true, dbg, true);
-    PSTAMP(4);
-    const bool live = (logPr != -INFINITY) && !isnan(logPr);  // model_def.cpp:472,476-480
     TablePtrs T;
     T.mults = a.mults; T.pairs = a.pairs; T.nh = a.nh; T.nn = a.nn; T.noise = a.noise;
     T.bg = a.bg; T.ntiles = a.ntiles; T.tile_bins = a.tile_bins;
-    wg_unpack(a.desc, s_params, U, slot, T, live, dbg, true);
+    // four roles beside each other (dev_unpack.h): prior terms + background tiles | table rows | shared scalars + m-visibilities
+    const double logPr = wg_log_prior(a.desc, s_params, U, true, dbg, true, &T, slot);
+    PSTAMP(4);
+    const bool live = (logPr != -INFINITY) && !isnan(logPr);  // model_def.cpp:472,476-480
+    wg_unpack(a.desc, s_params, U, slot, T, live, dbg, true, true);
     if (tid == 0) {
         *logPr_out = logPr;
         *status_out = *U.status;
@@ -296,9 +297,9 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
                     logL_new = (m == A) ? LB_TA : LA_TB;  // re-tempered value of the partner's likelihood
                     logPost_new = logL_new + logPr_new;
                 }
-                if (m == A && tid == 0) {
-                    a.counters[2] += 1;
-                    if (swapped) a.counters[3] += 1;
+                if (m == A && tid == 0) {  // (chain groups: launches of different iterations may overlap)
+                    atomicAdd((unsigned long long *)&a.counters[2], 1ull);
+                    if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
                 }
             }
         }

@@ -133,14 +133,36 @@ struct WaveSync {
     }
 };
 
+// Background series of every tile of evaluation slot `slot` (bg_series.h), tiles strided over lanes first .. first+nw-1.
+__device__ inline void wg_bg_tiles(const ModelDesc &d, const double *s_params, const mt::Shared *S, int slot, const TablePtrs &T, int first,
+                                   int nw) {
+    const int tid = threadIdx.x;
+    const double *np_ = s_params + S->L.o_noise;
+    const int nh = S->nharvey, nn = S->L.Nnoise;
+    if (tid >= first && tid < first + nw)
+        for (int t = tid - first; t < T.ntiles; t += nw) {
+            double xc, h;
+            bg::tile_geometry(t, T.tile_bins, d.x_first, d.step, xc, h);
+            if (!bg::series_valid(xc, h)) continue;
+            double o[bg::NH];
+            bg::tile_series([np_](int i) { return fabs(np_[i]); }, nh, nn, xc, h, o);
+            double *dst = T.bg + ((size_t)slot * T.ntiles + t) * bg::NH;
+#pragma unroll
+            for (int k = 0; k < bg::NH; k++) dst[k] = o[k];
+        }
+}
+
 // log-prior of the parameter vector in LDS (call_prior, model_def.cpp:421-464): returns the same value in every lane.
 // While the additive terms are summed, the LAST lane prepares the unpack's shared scalars (different wave: overlaps).
 // vis_in_prior: the LAST wave leaves the prior to the others and prepares the whole unpack instead (shared scalars AND the
 // m-visibilities): pass vis_done = true to wg_unpack afterwards.
+// early_rows (with vis_in_prior, 256 threads): a third group of lanes writes the table rows of slot `early_slot` while the
+// visibilities are still being computed, with hv = H; wg_unpack(rows_done = true) multiplies the visibilities in.
 __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, bool prepare_unpack, long *dbg = nullptr,
-                                      bool vis_in_prior = false) {
+                                      bool vis_in_prior = false, const TablePtrs *early_rows = nullptr, int early_slot = 0) {
     const int Np = d.Np;
     const bool split = vis_in_prior && prepare_unpack && blockDim.x >= 128 && (blockDim.x & 63) == 0;
+    const bool rows_early = split && early_rows && blockDim.x >= 256;
     const int tid = threadIdx.x, nt = split ? (int)blockDim.x - 64 : (int)blockDim.x;  // nt = lanes working on the prior
     if (tid >= nt) {  // wave-uniform: the helper wave, part 1 (beside the hard constraints)
         if (tid == nt) mt::shared_scalars_base(d.model_id, s_params, d.plength, *u.S);
@@ -168,12 +190,20 @@ __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params
     const int n_extra = (d.prior_class == 2) ? pr::ms_global_extra_terms(d.plength, d.extra) : 0;
     double f = 0;
     int st = TAMCMC_OK;
+    const int ntp = rows_early ? nt - 64 : nt;  // lanes on the additive terms
     if (tid >= nt) visibilities_stage(u, tid - nt, WaveSync());  // helper wave, part 2 (beside the additive terms)
-    else
-        for (int t = tid; t < Np + n_extra; t += nt) {
+    else if (tid >= ntp) {  // the wave before it: table rows that do not need the visibilities yet
+        for (int idx = tid - ntp; idx < d.per; idx += 64) {
+            const int rs = mt::build_multiplet(d.model_id, *u.poly, s_params, *u.S, idx, d.x_first, d.x_last, d.Nx, d.step,
+                                               &early_rows->mults[(size_t)early_slot * d.per + idx], true);
+            if (rs) st = rs;
+        }
+    } else
+        for (int t = tid; t < Np + n_extra; t += ntp) {
             if (t < Np) f = f + pr::generic_prior_term(s_params, Np, d.priors, d.priors_switch, t, &st);
             else f = f + pr::ms_global_extra_term(s_params, d.plength, d.extra, *u.dnu, t - Np);
         }
+    if (rows_early && early_rows->bg) wg_bg_tiles(d, s_params, u.S, early_slot, *early_rows, 0, ntp);  // the term lanes, once done
     if (st != TAMCMC_OK) *u.status = st;
     if (prepare_unpack && !split && tid == nt - 1) mt::shared_scalars_base(d.model_id, s_params, d.plength, *u.S);
     f = wg_sum(f, u.red);
@@ -183,36 +213,28 @@ __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params
 // params (LDS) -> table rows of evaluation slot `slot` (+ noise row, range, counts).  `live` = the prior is finite
 // (model_def.cpp:472,476-480 skips the model otherwise).  u.S must hold shared_scalars_base (wg_log_prior did it).
 __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, const UnpackLds &u, int slot, const TablePtrs &T,
-                                 bool live, long *dbg = nullptr, bool vis_done = false) {
+                                 bool live, long *dbg = nullptr, bool vis_done = false, bool rows_done = false) {
     const int tid = threadIdx.x, nt = blockDim.x, per = d.per;
     mt::Shared *S = u.S;
     if (live) {
         if (!vis_done) visibilities_stage(u, tid, WgSync());  // workgroup-uniform
         if (dbg && threadIdx.x == 0) dbg[5] = (long)wall_clock64();
-        for (int idx = tid; idx < per; idx += nt) {  // rows go straight to the likelihood kernel's table
-            const int st = mt::build_multiplet(d.model_id, *u.poly, s_params, *S, idx, d.x_first, d.x_last, d.Nx, d.step,
-                                               &T.mults[(size_t)slot * per + idx]);
-            if (st) *u.status = st;
-        }
+        if (rows_done) {  // rows already written with hv = H (wg_log_prior, early_rows): the visibilities are known now
+            for (int e = tid; e < per * 7; e += nt) {
+                tamcmc_multiplet *r = &T.mults[(size_t)slot * per + e / 7];
+                const int k = e % 7, l = r->l;
+                if (k < 2 * l + 1) r->hv[k] = r->hv[k] * S->ratios[l][k];
+            }
+        } else
+            for (int idx = tid; idx < per; idx += nt) {  // rows go straight to the likelihood kernel's table
+                const int st = mt::build_multiplet(d.model_id, *u.poly, s_params, *S, idx, d.x_first, d.x_last, d.Nx, d.step,
+                                                   &T.mults[(size_t)slot * per + idx]);
+                if (st) *u.status = st;
+            }
         if (dbg && threadIdx.x == 0) dbg[7] = (long)wall_clock64();
         for (int i = tid; i < S->L.Nnoise; i += nt) T.noise[(size_t)slot * d.stride + i] = fabs(s_params[S->L.o_noise + i]);
-        if (T.bg) {
-            // background series of every tile (bg_series.h): the lanes beyond the first wave, which builds the multiplets
-            const int first = (nt > 64) ? 64 : 0, nw = nt - first;
-            const double *np_ = s_params + S->L.o_noise;
-            const int nh = S->nharvey, nn = S->L.Nnoise;
-            if (tid >= first)
-                for (int t = tid - first; t < T.ntiles; t += nw) {
-                    double xc, h;
-                    bg::tile_geometry(t, T.tile_bins, d.x_first, d.step, xc, h);
-                    if (!bg::series_valid(xc, h)) continue;
-                    double o[bg::NH];
-                    bg::tile_series([np_](int i) { return fabs(np_[i]); }, nh, nn, xc, h, o);
-                    double *dst = T.bg + ((size_t)slot * T.ntiles + t) * bg::NH;
-#pragma unroll
-                    for (int k = 0; k < bg::NH; k++) dst[k] = o[k];
-                }
-        }
+        if (T.bg && !rows_done)  // (with early rows wg_log_prior's term lanes already did it)
+            wg_bg_tiles(d, s_params, S, slot, T, (nt > 64) ? 64 : 0, (nt > 64) ? nt - 64 : nt);  // beside the first wave's multiplet rows
     }
     __syncthreads();
     if (tid == 0) {

@@ -354,8 +354,9 @@ TM_HD xreal xabs(xreal v) { return v < 0 ? -v : v; }
 // ---------- one multiplet by index (reference accumulation order) ----------
 // aj: l-major (all l=0, then l=1, ...) models.cpp:1288-1376; Classic: n-major (l=0..lmax per order) :2026-2085;
 // local: l-major :3096-3159.
+// defer_ratio: leave hv[m] = H (the caller multiplies by the m-visibilities once they are known: same product, same bits)
 TM_HD int build_multiplet(int model_id, const PolyTab &T, const double *p, const Shared &S, int index, double x_first,
-                          double x_last, int64_t Nx, double step, tamcmc_multiplet *r) {
+                          double x_last, int64_t Nx, double step, tamcmc_multiplet *r, bool defer_ratio = false) {
     const Layout &L = S.L;
     int l = 0, n = 0;
     if (model_id == TAMCMC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC) {
@@ -428,7 +429,7 @@ TM_HD int build_multiplet(int model_id, const PolyTab &T, const double *p, const
             else nu = nu_nlm_a1etaa3(T, f, f_s, eta0, S.a3, l, m);
         }
         r->nu[m + l] = nu;
-        r->hv[m + l] = H * S.ratios[l][m + l];
+        r->hv[m + l] = defer_ratio ? H : H * S.ratios[l][m + l];
     }
     return TAMCMC_OK;
 }
