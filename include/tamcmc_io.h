@@ -21,6 +21,8 @@
 
 #include <stdint.h>
 
+struct tamcmc_sampler_config; /* include/tamcmc_sampler.h */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -62,6 +64,24 @@ int tamcmc_inputs_get(const tamcmc_inputs *in, double *params, int32_t *relax, d
 const char *tamcmc_inputs_name(const tamcmc_inputs *in, int i);        /* Input_Data.inputs_names[i] */
 const char *tamcmc_inputs_prior_name(const tamcmc_inputs *in, int i);  /* Input_Data.priors_names[i] */
 const char *tamcmc_inputs_model_name(const tamcmc_inputs *in);         /* Input_Data.model_fullname */
+
+/* ---------------- `.cfg` files ----------------
+ * Config/default/config_default.cfg dialect: `!Group:` lines, `key=value; comment` entries, '#' comment lines, `/END;`
+ * (Config::format_line + Config::read_cfg_file, tamcmc/sources/config.cpp:1062-1112, :1223-1732). */
+typedef struct tamcmc_cfg tamcmc_cfg;
+const char *tamcmc_cfg_last_error(void);
+int tamcmc_cfg_open(const char *path, tamcmc_cfg **out);
+void tamcmc_cfg_free(tamcmc_cfg *cfg);
+int tamcmc_cfg_string(const tamcmc_cfg *cfg, const char *group, const char *key, char *buf, int n);
+int tamcmc_cfg_numbers(const tamcmc_cfg *cfg, const char *group, const char *key, double *out, int max, int *n);
+/* !MALA, !Modeling (likelihood, prior class) and !Outputs (Nsamples, Nbuffer) -> the scalar fields of tamcmc_sampler_config
+ * (include/tamcmc_sampler.h);
+ * Nt_learn / periods_learn are written to the caller's buffers (max_learn entries) and linked into the struct. */
+int tamcmc_cfg_sampler(const tamcmc_cfg *cfg, struct tamcmc_sampler_config *out, int64_t *Nt_learn, int64_t *periods_learn,
+                       int max_learn, int64_t *Nsamples, int64_t *Nbuffer);
+/* Config/default/errors_default.cfg (Config::read_defautlerrors, config.cpp:2096-2150): initial proposal standard
+ * deviations err = A*value + B per FREE parameter, matched by name, 1 without a match (MALA::init_proposal, MALA.cpp:246-262). */
+int tamcmc_io_init_errors(const char *errors_path, const char *const *names, const double *values, int64_t nvars, double *errors);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,13 @@ EXTRA_ABI += [
     ("tamcmc_io_load_model_local", C.c_int, [C.c_char_p, C.c_int, C.c_double, C.POINTER(_vp)]),
     ("tamcmc_io_load_model_global", C.c_int, [C.c_char_p, C.c_double, C.POINTER(_vp)]),
     ("tamcmc_inputs_free", None, [_vp]),
+    ("tamcmc_cfg_last_error", C.c_char_p, []),
+    ("tamcmc_cfg_open", C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    ("tamcmc_cfg_free", None, [_vp]),
+    ("tamcmc_cfg_string", C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
+    ("tamcmc_cfg_numbers", C.c_int, [_vp, C.c_char_p, C.c_char_p, _dp, C.c_int, C.POINTER(C.c_int)]),
+    ("tamcmc_cfg_sampler", C.c_int, [_vp, _vp, _i64p, _i64p, C.c_int, _i64p, _i64p]),
+    ("tamcmc_io_init_errors", C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), _dp, C.c_int64, _dp]),
     ("tamcmc_inputs_nparams", C.c_int, [_vp]),
     ("tamcmc_inputs_get", C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip, _dp, _dp, _ip, _ip, _dp, _dp]),
     ("tamcmc_inputs_name", C.c_char_p, [_vp, C.c_int]),
@@ -136,3 +143,62 @@ def load_local_star(model_path, data_path, slice_ind=0, x_col=0, y_col=1):
                 inp.extra_priors)
     star.y = np.ascontiguousarray(tab[a:b, y_col])
     return star, inp
+
+
+class Cfg:
+    """A `.cfg` file of the reference's dialect (`!Group:` / `key=value; comment`)."""
+
+    def __init__(self, path):
+        self._L = _L()
+        self._h = _vp()
+        rc = self._L.tamcmc_cfg_open(str(path).encode(), C.byref(self._h))
+        if rc != 0:
+            raise TamcmcError(rc, "cfg_open: " + self._L.tamcmc_cfg_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._L.tamcmc_cfg_free(self._h)
+            self._h = None
+
+    def string(self, group, key):
+        buf = C.create_string_buffer(512)
+        rc = self._L.tamcmc_cfg_string(self._h, group.encode(), key.encode(), buf, 512)
+        if rc != 0:
+            raise KeyError("%s/%s: %s" % (group, key, self._L.tamcmc_cfg_last_error().decode()))
+        return buf.value.decode()
+
+    def numbers(self, group, key, max_n=16):
+        out = np.zeros(max_n)
+        n = C.c_int(0)
+        rc = self._L.tamcmc_cfg_numbers(self._h, group.encode(), key.encode(), _p(out), max_n, C.byref(n))
+        if rc != 0:
+            raise KeyError("%s/%s: %s" % (group, key, self._L.tamcmc_cfg_last_error().decode()))
+        return out[:n.value].copy()
+
+    def sampler_kwargs(self):
+        """The !MALA / !Modeling / !Outputs settings as keyword arguments of `Sampler` (+ Nsamples, Nbuffer, prior_class)."""
+        from .sampler import SamplerConfig
+        sc = SamplerConfig()
+        nt = np.zeros(16, dtype=np.int64)
+        pe = np.zeros(16, dtype=np.int64)
+        ns, nb = C.c_int64(0), C.c_int64(0)
+        rc = self._L.tamcmc_cfg_sampler(self._h, C.addressof(sc), _p(nt, _i64p), _p(pe, _i64p), 16, C.byref(ns), C.byref(nb))
+        if rc != 0:
+            raise TamcmcError(rc, "cfg_sampler: " + self._L.tamcmc_cfg_last_error().decode())
+        n = sc.n_Nt_learn
+        return dict(nchains=sc.Nchains, lambda_temp=sc.lambda_temp, use_drift=sc.use_drift, p=sc.likelihood_params,
+                    target_acceptance=sc.target_acceptance, c0=sc.c0, epsilon1=sc.epsilon1, epsilon2=sc.epsilon2, A1=sc.A1,
+                    delta=sc.delta, delta_x=sc.delta_x, dN_mixing=int(sc.dN_mixing), Nt_learn=tuple(int(v) for v in nt[:n]),
+                    periods_learn=tuple(int(v) for v in pe[:n - 1])), dict(Nsamples=ns.value, Nbuffer=nb.value,
+                                                                            prior_class=sc.prior_class, likelihood_id=sc.likelihood_id)
+
+
+def init_errors(errors_path, star):
+    """Initial proposal standard deviations of the star's free parameters from an errors_default.cfg-style file."""
+    L = _L()
+    idx = star.index_to_relax
+    names = (C.c_char_p * len(idx))(*[star.names[i].encode() for i in idx])
+    vals = np.ascontiguousarray(star.params[idx], dtype=np.float64)
+    out = np.zeros(len(idx))
+    _check(L.tamcmc_io_init_errors(str(errors_path).encode(), names, _p(vals), len(idx), _p(out)), "init_errors")
+    return out

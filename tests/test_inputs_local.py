@@ -139,3 +139,37 @@ def test_global_model_aj(inputs, pkg):
         inputs.GlobalInputs(MODEL, resol)           # eight '*' ranges: not a global-fit file (io_ms_global.cpp:93-104)
     with pytest.raises(Exception):
         inputs.LocalInputs(SUN, 0, resol)           # the loaders refuse each other's model_fullname
+
+
+def test_cfg_dialect_and_sampler_settings(inputs):
+    """`.cfg` reader (Config::format_line / read_cfg_file, config.cpp:1062-1112, :1223-1732) on a fixture written for this test."""
+    c = inputs.Cfg(os.path.join(GOLD, "sampler_test.cfg"))
+    assert c.string("MALA", "proposal_type") == "Random"
+    assert c.numbers("MALA", "lambda_temp")[0] == 3.5                  # "3.50 #1.70; ..." : the value is the leading number
+    assert list(c.numbers("MALA", "Nt_learn")) == [200, 600, 4000] and list(c.numbers("MALA", "periods_learn")) == [1, 5]
+    assert c.numbers("Data", "ysig_col")[0] == -1 and c.string("Outputs", "file_format") == "binary"
+    with pytest.raises(KeyError):
+        c.string("MALA", "ignored")                                        # after /END;
+    with pytest.raises(KeyError):
+        c.string("MALA", "no_such_key")
+    kw, rest = c.sampler_kwargs()
+    assert kw == dict(nchains=4, lambda_temp=3.5, use_drift=0, p=1.0, target_acceptance=0.234, c0=5.0, epsilon1=1e-12, epsilon2=1e-12,
+                      A1=1e14, delta=0.0, delta_x=1e-10, dN_mixing=1, Nt_learn=(200, 600, 4000), periods_learn=(1, 5))
+    assert rest == dict(Nsamples=150, Nbuffer=10000, prior_class=3, likelihood_id=0)   # io_local, chi(2,2p)
+    c.close()
+    with pytest.raises(Exception):
+        inputs.Cfg(os.path.join(GOLD, "missing.cfg"))
+
+
+def test_initial_errors_from_the_errors_file(inputs):
+    """err = A*value + B by parameter name, 1 without a match (Config::read_defautlerrors + MALA::init_proposal)."""
+    star, inp = inputs.load_local_star(MODEL, DATA, 0)
+    e = inputs.init_errors(os.path.join(GOLD, "errors_test.cfg"), star)
+    idx = list(star.index_to_relax)
+    names = [star.names[i] for i in idx]
+    assert names == ["Height_l", "Height_l", "Frequency_l", "Frequency_l", "sqrt(splitting_a1).cosi", "sqrt(splitting_a1).sini", "Width_l",
+                     "Width_l", "White_Noise_N0"]
+    v = star.params[idx]
+    want = [0.02 * v[0] + 0.01, 0.02 * v[1] + 0.01, 0.07, 0.07, 0.1 * v[4] + 0.05, 1.0, 0.015 * v[6] + 0.005, 0.015 * v[7] + 0.005,
+            0.015 * v[8] + 0.0002]                                          # ".sini" has no row in this fixture -> 1
+    assert np.allclose(e, want, rtol=1e-15)
