@@ -5,7 +5,17 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 lines = [f"# rocprofv3 summary {tag} (MI355X, one GPU)", ""]
-ks = glob.glob(f"{src}/trace/*/*kernel_stats.csv")
+def newest(pattern):
+    """gpurun merges new files over old ones: keep the files of the highest run id only."""
+    fs = glob.glob(pattern)
+    if not fs:
+        return []
+    rid = lambda f: int(os.path.basename(f).split("_")[0]) if os.path.basename(f).split("_")[0].isdigit() else -1
+    top = max(rid(f) for f in fs)
+    return [f for f in fs if rid(f) == top]
+
+
+ks = newest(f"{src}/trace/*/*kernel_stats.csv")
 if ks:
     lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --mala-steps 0`", "",
               "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
@@ -20,7 +30,7 @@ except Exception as e:
     lines += [f"(no bench.json: {e})", ""]
 agg = collections.defaultdict(list)
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
-    for f in glob.glob(f"{src}/{d}/*/*counter_collection.csv"):
+    for f in newest(f"{src}/{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if "k_loglike<1, 64, 8, false" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
