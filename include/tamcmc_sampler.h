@@ -70,6 +70,22 @@ int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL
 /* proposal law of chain m: mu [Nvars], covarmat [Nvars x Nvars] (restore file content, outputs.cpp:863-1025) */
 int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, double *covarmat);
 int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, const double *covarmat, double sigma);
+/* Chain positions vars [Nchains x Nvars] from outside (restart): priors and likelihoods are re-evaluated on the device;
+ * iteration >= 0 also sets the iteration counter (the learning schedule and gamma = c0/(1+i) depend on it). */
+int tamcmc_sampler_set_state(tamcmc_sampler *s, const double *vars, int64_t iteration);
+
+/* ---- checkpoint / resume: the reference's restore files <root>1.dat (positions), <root>2.dat (sigmas, mus), <root>3.dat
+ * (covariance matrices) -- Outputs::write_buffer_restore outputs.cpp:863-1025, Config::read_restore_files config.cpp:1734-1990.
+ * Written with 17 significant digits (the reference: 6); the *_mean blocks repeat the last values. */
+int tamcmc_outputs_write_restore(const char *root, int32_t Nchains, int32_t Nvars, int64_t iteration, const char *const *names,
+                                 const double *vars, const double *sigmas, const double *mus, const double *covarmats);
+/* sizes always; arrays (may be NULL): vars [Nchains x Nvars], sigmas [Nchains], mus [Nchains x Nvars], covarmats [Nchains x Nvars^2] */
+int tamcmc_outputs_read_restore(const char *root, int32_t *Nchains, int32_t *Nvars, int64_t *iteration, double *vars, double *sigmas,
+                                double *mus, double *covarmats);
+int tamcmc_sampler_write_restore(const tamcmc_sampler *s, const char *root, const char *const *var_names);
+/* the three switches of the reference's !Outputs section: do_restore_variables, do_restore_proposal, do_restore_last_index */
+int tamcmc_sampler_read_restore(tamcmc_sampler *s, const char *root, int32_t restore_variables, int32_t restore_proposal,
+                                int32_t restore_last_index);
 
 /* ---- the reference's on-disk sample formats (outputs.cpp:1231-1333, :1472-1550) and summary statistics ---- */
 /* <root>params.hdr + <root>params_chain-<m>.bin: raw little-endian doubles [sample][var]; samples = [n x Nchains x Nvars]

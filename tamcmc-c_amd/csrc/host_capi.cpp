@@ -195,6 +195,64 @@ int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, 
     return TAMCMC_OK;
 }
 
+// Chain positions (and optionally the iteration counter) from outside: restart / resume (Config::read_restore_files +
+// Model_def constructor path of the reference, config.cpp:1734-1990, MALA.cpp:100-131).  Re-evaluates prior and likelihood.
+int tamcmc_sampler_set_state(tamcmc_sampler *s, const double *vars, int64_t iteration) {
+    if (!s || !vars) return TAMCMC_ERR_BAD_ARG;
+    const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    for (long m = 0; m < Nc; m++) {
+        std::memcpy(s->cur->vars.row(m), vars + (size_t)m * Nv, (size_t)Nv * sizeof(double));
+        s->cur->update_params_with_vars(m);
+        s->mala->invalidate((int)m);  // cached gradient of the old position
+    }
+    int rc = s->cur->generate_models_batch(&s->cfg.data.data, s->mala->Tcoefs);
+    if (rc) return rc;
+    if (iteration >= 0) s->mala->iteration = (long)iteration;
+    if (s->dev) {
+        rc = s->dev->upload_state(s->cur->vars.a.data(), s->cur->params.a.data(), s->cur->logLikelihood.data(), s->cur->logPrior.data(),
+                                  s->cur->logPosterior.data(), s->cur->init_logLikelihood.data());
+        if (rc) return rc;
+    }
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_write_restore(const tamcmc_sampler *s, const char *root, const char *const *var_names) {
+    if (!s || !root) return TAMCMC_ERR_BAD_ARG;
+    const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    std::vector<double> mus((size_t)(Nc * Nv)), covs((size_t)(Nc * Nv * Nv));
+    for (long m = 0; m < Nc; m++) {
+        std::memcpy(mus.data() + (size_t)(m * Nv), s->mala->mu.row(m), (size_t)Nv * sizeof(double));
+        std::memcpy(covs.data() + (size_t)(m * Nv * Nv), s->mala->covarmat[(size_t)m].a.data(), (size_t)(Nv * Nv) * sizeof(double));
+    }
+    return tamcmc_outputs_write_restore(root, (int32_t)Nc, (int32_t)Nv, s->mala->iteration, var_names, s->cur->vars.a.data(),
+                                        s->mala->sigma.data(), mus.data(), covs.data());
+}
+
+// do_restore_variables / do_restore_proposal / do_restore_last_index of the reference's !Outputs section (config.cpp:1780-1790)
+int tamcmc_sampler_read_restore(tamcmc_sampler *s, const char *root, int32_t restore_variables, int32_t restore_proposal,
+                                int32_t restore_last_index) {
+    if (!s || !root) return TAMCMC_ERR_BAD_ARG;
+    const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    int32_t nc = 0, nv = 0;
+    int64_t it = 0;
+    int rc = tamcmc_outputs_read_restore(root, &nc, &nv, &it, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (nc != Nc || nv != Nv) return TAMCMC_ERR_BAD_ARG;  // a restart needs the same chains and variables
+    std::vector<double> vars((size_t)(Nc * Nv)), sig((size_t)Nc), mus((size_t)(Nc * Nv)), covs((size_t)(Nc * Nv * Nv));
+    rc = tamcmc_outputs_read_restore(root, &nc, &nv, &it, vars.data(), sig.data(), mus.data(), covs.data());
+    if (rc) return rc;
+    if (restore_proposal)
+        for (long m = 0; m < Nc; m++) {
+            rc = tamcmc_sampler_set_proposal(s, (int32_t)m, mus.data() + (size_t)(m * Nv), covs.data() + (size_t)(m * Nv * Nv), sig[(size_t)m]);
+            if (rc) return rc;
+        }
+    if (restore_variables) {
+        rc = tamcmc_sampler_set_state(s, vars.data(), restore_last_index ? it : -1);
+        if (rc) return rc;
+    } else if (restore_last_index) s->mala->iteration = (long)it;
+    return TAMCMC_OK;
+}
+
 double tamcmc_log_prior(int prior_class, const double *params, int64_t Nparams, const int32_t *plength, const double *priors,
                         const int32_t *priors_switch, const double *extra_priors, int32_t n_extra, int32_t *status) {
     if (status) *status = TAMCMC_OK;

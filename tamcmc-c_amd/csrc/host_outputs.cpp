@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -137,3 +138,139 @@ int tamcmc_params_summary(const double *samples, int64_t n, int32_t Nvars, int64
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Restore files (checkpoint / resume): <root>1.dat = chain positions, <root>2.dat = sigmas and mus, <root>3.dat = covariance
+// matrices; layout of Outputs::write_buffer_restore (tamcmc/sources/outputs.cpp:863-1025), read back as
+// Config::read_restore_files does (config.cpp:1734-1990): '#' comment lines, "! key= value" lines, matrix rows, "*<chain>"
+// block markers.  Two deliberate differences: numbers are written with 17 significant digits (the reference streams Eigen
+// rows at the default 6, so its restart is lossy), and the *_mean blocks (averages over the reference's output buffer, which
+// this build does not keep) repeat the last values.
+namespace {
+void restore_header(std::ofstream &f, int file_no, const char *what, int Nchains, int Nvars, int64_t iteration, const char *const *names) {
+    f << "# This is an output file containing what is required to restore a run to its last saved position \n";
+    f << "# File number: " << file_no << " \n";
+    f << "# Contains " << what << "\n";
+    f << "! Nchains= " << Nchains << "\n";
+    f << "! Nvars= " << Nvars << "\n";
+    f << "! iteration=" << iteration << "\n";
+    f << "! variable_names=";
+    for (int i = 0; i < Nvars; i++) f << (names && names[i] ? names[i] : "var") << "   ";
+    f << "\n";
+}
+void put_row(std::ofstream &f, const double *v, int n) {
+    char buf[40];
+    for (int i = 0; i < n; i++) {
+        std::snprintf(buf, sizeof buf, "%.17g", v[i]);
+        f << (i ? " " : "") << buf;
+    }
+    f << "\n";
+}
+// numbers following `key` in a restore file: on the key's own line after '=', then on the following lines until the next
+// line starting with '!' or '#'; lines starting with '*' (chain markers) are skipped
+bool read_block(const std::string &path, const std::string &key, size_t want, std::vector<double> &out, int *Nchains, int *Nvars,
+                int64_t *iteration) {
+    std::ifstream f(path.c_str());
+    if (!f.is_open()) return false;
+    out.clear();
+    bool in_block = false;
+    for (std::string ln; std::getline(f, ln);) {
+        size_t a = ln.find_first_not_of(" \t\r");
+        if (a == std::string::npos) continue;
+        if (ln[a] == '#') { in_block = false; continue; }
+        if (ln[a] == '!') {
+            const size_t eq = ln.find('=');
+            std::string k = ln.substr(a, eq == std::string::npos ? std::string::npos : eq - a);
+            while (!k.empty() && (k.back() == ' ' || k.back() == '\t')) k.pop_back();
+            const std::string rest = eq == std::string::npos ? "" : ln.substr(eq + 1);
+            if (k == "! Nchains" && Nchains) *Nchains = std::atoi(rest.c_str());
+            if (k == "! Nvars" && Nvars) *Nvars = std::atoi(rest.c_str());
+            if (k == "! iteration" && iteration) *iteration = std::atoll(rest.c_str());
+            in_block = (k == "! " + key);
+            if (in_block) {
+                std::istringstream is(rest);
+                for (double v; is >> v;) out.push_back(v);
+            }
+            continue;
+        }
+        if (!in_block || ln[a] == '*') continue;
+        std::istringstream is(ln);
+        for (double v; is >> v;) out.push_back(v);
+    }
+    return out.size() == want;
+}
+}  // namespace
+
+extern "C" int tamcmc_outputs_write_restore(const char *root, int32_t Nchains, int32_t Nvars, int64_t iteration, const char *const *names,
+                                            const double *vars, const double *sigmas, const double *mus, const double *covarmats) {
+    if (!root || !vars || !sigmas || !mus || !covarmats || Nchains < 1 || Nvars < 1) return TAMCMC_ERR_BAD_ARG;
+    const std::string base(root);
+    {
+        std::ofstream f((base + "1.dat").c_str());
+        if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
+        restore_header(f, 1, "the last values for the variables vars[0:Nchain-1]. vars_mean denotes averaged values of Nbuffer", Nchains, Nvars,
+                       iteration, names);
+        for (const char *key : {"! vars= ", "! vars_mean= "}) {
+            f << key << "\n";
+            for (int m = 0; m < Nchains; m++) put_row(f, vars + (size_t)m * Nvars, Nvars);
+        }
+    }
+    {
+        std::ofstream f((base + "2.dat").c_str());
+        if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
+        restore_header(f, 2, "the last values of (a) sigmas[0:Nchains-1] and (b) mus[0:Nchains-1, 0:Nvars-1]", Nchains, Nvars, iteration, names);
+        for (int pass = 0; pass < 2; pass++) {
+            f << (pass ? "! sigmas_mean= " : "! sigmas= ");
+            put_row(f, sigmas, Nchains);
+            f << (pass ? "! mus_mean= " : "! mus= ") << "\n";
+            for (int m = 0; m < Nchains; m++) put_row(f, mus + (size_t)m * Nvars, Nvars);
+        }
+    }
+    {
+        std::ofstream f((base + "3.dat").c_str());
+        if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
+        restore_header(f, 3, "the last value of the covariance matrix covarmats[0:Nchains-1, 0:Nvars-1, 0:Nvars-1]", Nchains, Nvars, iteration,
+                       names);
+        for (const char *key : {"! covarmats= ", "! covarmats_mean= "}) {
+            f << key << "\n";
+            for (int m = 0; m < Nchains; m++) {
+                f << "*" << m << "\n";
+                for (int i = 0; i < Nvars; i++) put_row(f, covarmats + ((size_t)m * Nvars + i) * Nvars, Nvars);
+            }
+        }
+    }
+    return TAMCMC_OK;
+}
+
+// Sizes first (arrays may be NULL), then the arrays: vars [Nchains x Nvars], sigmas [Nchains], mus [Nchains x Nvars],
+// covarmats [Nchains x Nvars x Nvars].
+extern "C" int tamcmc_outputs_read_restore(const char *root, int32_t *Nchains, int32_t *Nvars, int64_t *iteration, double *vars, double *sigmas,
+                                           double *mus, double *covarmats) {
+    if (!root || !Nchains || !Nvars) return TAMCMC_ERR_BAD_ARG;
+    const std::string base(root);
+    int nc = 0, nv = 0;
+    int64_t it = 0;
+    std::vector<double> tmp;
+    read_block(base + "1.dat", "\x01none", 0, tmp, &nc, &nv, &it);  // header scan
+    if (nc < 1 || nv < 1) return TAMCMC_ERR_BAD_ARG;
+    *Nchains = nc; *Nvars = nv;
+    if (iteration) *iteration = it;
+    const size_t C = (size_t)nc, V = (size_t)nv;
+    if (vars) {
+        if (!read_block(base + "1.dat", "vars", C * V, tmp, nullptr, nullptr, nullptr)) return TAMCMC_ERR_BAD_ARG;
+        std::copy(tmp.begin(), tmp.end(), vars);
+    }
+    if (sigmas) {
+        if (!read_block(base + "2.dat", "sigmas", C, tmp, nullptr, nullptr, nullptr)) return TAMCMC_ERR_BAD_ARG;
+        std::copy(tmp.begin(), tmp.end(), sigmas);
+    }
+    if (mus) {
+        if (!read_block(base + "2.dat", "mus", C * V, tmp, nullptr, nullptr, nullptr)) return TAMCMC_ERR_BAD_ARG;
+        std::copy(tmp.begin(), tmp.end(), mus);
+    }
+    if (covarmats) {
+        if (!read_block(base + "3.dat", "covarmats", C * V * V, tmp, nullptr, nullptr, nullptr)) return TAMCMC_ERR_BAD_ARG;
+        std::copy(tmp.begin(), tmp.end(), covarmats);
+    }
+    return TAMCMC_OK;
+}

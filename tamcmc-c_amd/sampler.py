@@ -28,6 +28,11 @@ EXTRA_ABI += [
     ("tamcmc_sampler_get_state", C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _i64p]),
     ("tamcmc_sampler_get_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp]),
     ("tamcmc_sampler_set_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_double]),
+    ("tamcmc_sampler_set_state", C.c_int, [_vp, _dp, C.c_int64]),
+    ("tamcmc_outputs_write_restore", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_char_p), _dp, _dp, _dp, _dp]),
+    ("tamcmc_outputs_read_restore", C.c_int, [C.c_char_p, _ip, _ip, _i64p, _dp, _dp, _dp, _dp]),
+    ("tamcmc_sampler_write_restore", C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_char_p)]),
+    ("tamcmc_sampler_read_restore", C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]),
     ("tamcmc_outputs_write_params", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, C.c_int64, _dp,
                                              C.POINTER(C.c_char_p), C.c_int32]),
     ("tamcmc_outputs_write_stat_criteria", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32]),
@@ -119,6 +124,26 @@ class Sampler:
                                          _p(out["Pmove"]), _p(out["sigma"]), _p(cnt, _i64p))
         out.update(iteration=int(cnt[0]), accepted0=int(cnt[1]), swap_attempts=int(cnt[2]), swaps=int(cnt[3]))
         return out
+
+    def set_state(self, vars, iteration=-1):
+        v = _f64(vars)
+        rc = self._L.tamcmc_sampler_set_state(self._h, _p(v), int(iteration))
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_set_state")
+
+    def write_restore(self, root, names=None):
+        """Checkpoint: <root>1.dat / 2.dat / 3.dat in the reference's restore-file layout."""
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        rc = self._L.tamcmc_sampler_write_restore(self._h, str(root).encode(), arr)
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_write_restore")
+
+    def read_restore(self, root, variables=True, proposal=True, last_index=True):
+        rc = self._L.tamcmc_sampler_read_restore(self._h, str(root).encode(), int(variables), int(proposal), int(last_index))
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_read_restore")
 
     def get_proposal(self, m):
         mu, cov = np.zeros(self.nvars), np.zeros((self.nvars, self.nvars))

@@ -164,3 +164,38 @@ def test_forty_chains_device_engine(pkg, oracle, synth, ctx):
     moved = [(smp[1:, m] != smp[:-1, m]).any() for m in range(40)]
     assert all(moved)
     s.close()
+
+
+@pytest.mark.parametrize("engine", ["host", "device"])
+def test_checkpoint_and_resume(pkg, oracle, synth, ctx, tmp_path, engine):
+    """write_restore after 120 iterations (adaptation running), a NEW sampler reads the files and continues: it must follow the
+    uninterrupted run (random numbers are addressed by (seed, chain, iteration); a swapped chain's re-tempered logL is
+    recomputed from scratch on restart, so agreement is to rounding until a knife-edge decision)."""
+    star = _star_with_data(pkg, oracle, synth)
+    ctx.set_spectrum(star.x, star.y)
+    kw = dict(nchains=5, lambda_temp=1.6, seed=17, Nt_learn=(30, 400), periods_learn=(1,), dN_mixing=2, engine=engine)
+    a = pkg.Sampler(ctx, star, **kw)
+    a.run(120, record=False)
+    root = str(tmp_path / "restore_")
+    a.write_restore(root, [star.names[i] for i in star.index_to_relax])
+    sa, ta = a.run(80, stats=True)
+    b = pkg.Sampler(ctx, star, **kw)
+    b.read_restore(root)
+    st = b.state()
+    assert st["iteration"] == 120
+    mu_a, cov_a = a.get_proposal(1)
+    sb, tb = b.run(80, stats=True)
+    same = np.all(np.isclose(sa, sb, rtol=1e-9, atol=1e-12), axis=(1, 2))
+    first_div = 80 if same.all() else int(np.argmin(same))
+    assert first_div >= 40, f"resumed run diverges at iteration {first_div}"
+    assert np.allclose(ta[:first_div], tb[:first_div], rtol=1e-9, atol=1e-7)
+    assert b.state()["iteration"] == 200
+    # restoring only the proposal law keeps the fresh start point and iteration 0
+    c = pkg.Sampler(ctx, star, **kw)
+    v0 = c.state()["vars"].copy()
+    c.read_restore(root, variables=False, proposal=True, last_index=False)
+    assert c.state()["iteration"] == 0 and np.array_equal(c.state()["vars"], v0)
+    mu_r, cov_r = c.get_proposal(1)
+    mu_b, cov_b = pkg.Sampler(ctx, star, **kw).get_proposal(1)
+    assert not np.allclose(cov_r, cov_b)     # the adapted covariance replaced the initial diagonal one
+    a.close(); b.close(); c.close()

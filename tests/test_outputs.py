@@ -28,3 +28,30 @@ def test_params_bin_hdr_roundtrip_and_summary(pkg, synth, tmp_path):
     assert np.allclose(sd, smp[:, 0, :].std(0), rtol=1e-13)        # population standard deviation, like the reference tool
     mean2, med2, _ = sampler.params_summary(smp[:256, 0, :])       # even count: median = mean of the two central values
     assert np.allclose(med2, np.median(smp[:256, 0, :], axis=0), rtol=1e-15)
+
+
+def test_restore_files_round_trip(pkg, tmp_path):
+    """Checkpoint files in the layout of Outputs::write_buffer_restore (outputs.cpp:863-1025), read back as
+    Config::read_restore_files does (config.cpp:1734-1990); 17 significant digits -> exact round trip."""
+    import ctypes as C
+    from tamcmc_c_amd import sampler as S
+    L = S._rebind()
+    rng = np.random.default_rng(4)
+    nc, nv, it = 3, 5, 1234
+    vars_, sig, mus = rng.standard_normal((nc, nv)) * 1e3, rng.uniform(0.1, 2, nc), rng.standard_normal((nc, nv))
+    cov = rng.standard_normal((nc, nv, nv)) * 1e-3
+    names = (C.c_char_p * nv)(*[("v%d" % i).encode() for i in range(nv)])
+    root = str(tmp_path / "restore_")
+    assert L.tamcmc_outputs_write_restore(root.encode(), nc, nv, it, names, S._p(vars_), S._p(sig), S._p(mus), S._p(cov)) == 0
+    txt = open(root + "1.dat").read()
+    assert "! Nchains= 3" in txt and "! Nvars= 5" in txt and "! iteration=1234" in txt and "! variable_names=v0   v1" in txt
+    assert "! vars= " in txt and "! vars_mean= " in txt and "*2" in open(root + "3.dat").read() and "! sigmas= " in open(root + "2.dat").read()
+    a, b, c = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int64)
+    assert L.tamcmc_outputs_read_restore(root.encode(), S._p(a, S._ip), S._p(b, S._ip), S._p(c, S._i64p), None, None, None, None) == 0
+    assert (a[0], b[0], c[0]) == (nc, nv, it)
+    v2, s2, m2, c2 = np.zeros((nc, nv)), np.zeros(nc), np.zeros((nc, nv)), np.zeros((nc, nv, nv))
+    assert L.tamcmc_outputs_read_restore(root.encode(), S._p(a, S._ip), S._p(b, S._ip), S._p(c, S._i64p), S._p(v2), S._p(s2), S._p(m2),
+                                         S._p(c2)) == 0
+    assert np.array_equal(v2, vars_) and np.array_equal(s2, sig) and np.array_equal(m2, mus) and np.array_equal(c2, cov)
+    assert L.tamcmc_outputs_read_restore(str(tmp_path / "absent_").encode(), S._p(a, S._ip), S._p(b, S._ip), S._p(c, S._i64p), None, None,
+                                         None, None) != 0
