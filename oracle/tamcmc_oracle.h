@@ -41,6 +41,7 @@ extern "C" {
 #define ORC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC 3
 #define ORC_MODEL_MS_LOCAL_BASIC 11
 #define ORC_MODEL_MS_GLOBAL_AJ 23
+#define ORC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 25
 
 /* ---- scalar helpers ---- */
 long double orc_Pslm(int s, int l, int m);               /* acoefs.cpp:51-110 */
@@ -91,6 +92,30 @@ int orc_model_MS_local_basic(const double *params, const int *plength, const dou
                              double *model); /* models.cpp:3012-3195 */
 int orc_call_model(int model_id, const double *params, const int *plength, const double *x, long Nx,
                    double *model); /* model_def.cpp:220-388 */
+
+/* ---- red-giant model and its host pre-step (armm_oracle.c; parity unpinned, see that file's header) ---- */
+typedef struct orc_eigensols {  /* Data_eigensols, external/ARMM/data_solver.h */
+    long n_m, n_p, n_g;
+    double *nu_m, *nu_p, *nu_g, *dnup, *dPg;
+} orc_eigensols;
+void orc_eigensols_free(orc_eigensols *e);
+int orc_armm_solve_O2p(double Dnu_p, double epsilon, int el, double delta0l, double alpha_p, double nmax, double DPl, double alpha,
+                       double q, double fmin, double fmax, double resol, orc_eigensols *out);      /* solver_mm.cpp:470-611 */
+int orc_armm_solve_O2from_l0(const double *nu_l0, long n0, int el, double delta0l, double DPl, double alpha, double q, double resol,
+                             double freq_min, double freq_max, orc_eigensols *out);               /* solver_mm.cpp:624-760 */
+void orc_ksi_fct2_precise(const double *nu, long n, const double *nu_p, const double *Dnu_p, long Lp, const double *nu_g,
+                          const double *DPl, long Lg, double q, double *ksi);                      /* bump_DP.cpp:125-188 */
+double orc_spline_eval(const double *xn, const double *yn, long n, int type /*1 cubic, 2 Hermite*/, double x); /* spline.h:242-498 */
+typedef struct orc_rgb_modes {  /* what the model function derives before it sums Lorentzians (models.cpp:4770-4913) */
+    long N0, N1;
+    double *fl0, *Wl0, *Hl0;                    /* radial modes */
+    double *fl1, *Wl1, *Hl1, *a1_l1, *ksi;      /* l=1 mixed modes: frequency (+bias), width, height, splitting, zeta */
+    double g[6];                                /* |width-law parameters| */
+} orc_rgb_modes;
+int orc_rgb_v4_modes(const double *params, const int *plength, double step, orc_rgb_modes *out);
+void orc_rgb_modes_free(orc_rgb_modes *m);
+int orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(const double *params, const int *plength, const double *x, long Nx,
+                                                   double *model);                                  /* models.cpp:4684-5079 */
 
 /* call_likelihood (model_def.cpp:390-419): chi22p / Tcoef */
 double orc_call_likelihood(const double *y, const double *model, long Nx, double likelihood_params, double Tcoef);

@@ -8,7 +8,7 @@ y = M(theta_true) * Exp(1) with M supplied by the caller (GPU path in bench.py, 
 """
 import numpy as np
 
-MODEL_CLASSIC, MODEL_LOCAL, MODEL_AJ = 3, 11, 23
+MODEL_CLASSIC, MODEL_LOCAL, MODEL_AJ, MODEL_RGB_V4 = 3, 11, 23, 25
 KEPLER_4YR_RESOL = 1e6 / (4.0 * 365.0 * 86400.0)  # test_build_l_mode.cpp:107
 
 
@@ -194,3 +194,29 @@ def aj_to_classic(params, plength):
     pl = plength.copy()
     pl[6] = 6
     return out, pl
+
+
+def make_params_rgb_model(rng, nmax=6, dnu=20.0, epsilon=0.2, n_first=6, delta0l=-0.6, DPl=80.0, alpha_g=0.0, q=0.15, nferr=4,
+                          bias_type=0, model_type=0, rot_env=0.1, rot_core=0.6, inclination=55.0, trunc_c=20.0, ferr_scale=0.05):
+    """Parameter vector of model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (layout: SURVEY App. B; generator in the spirit of
+    make_params_RGB_model, test/lorentzian_test/unit_tests/test_build_l_mode.cpp:584-767): nmax radial orders, the l=1 block
+    [delta0l, DPl, alpha_g, q, -, -, Wfactor, Hfactor, fref x nferr, ferr x nferr], l=2/l=3 lists of nmax-1 modes, ten
+    rotation/asymmetry slots, the six-parameter Appourchaux width law, two Harvey profiles + white noise."""
+    n = np.arange(nmax)
+    fl0 = (n_first + n + epsilon) * dnu + rng.uniform(-0.01, 0.01, nmax) * dnu
+    numax = fl0.mean()
+    heights = 40.0 * np.exp(-0.5 * ((fl0 - numax) / (1.2 * dnu)) ** 2) + 2.0
+    vis = np.array([1.5, 0.53, 0.08])
+    fref = (n_first + 1 + np.arange(nferr) * max((nmax - 2) / max(nferr - 1, 1), 1) + epsilon + 0.5) * dnu
+    ferr = rng.uniform(-ferr_scale, ferr_scale, nferr) if bias_type != 0 else np.zeros(nferr)
+    l1 = np.concatenate([[delta0l, DPl, alpha_g, q, 0.0, 0.0, 1.0, 1.0], fref, ferr])
+    fl2 = fl0[1:] - 0.12 * dnu
+    fl3 = fl0[:-1] + 0.21 * dnu
+    split = np.array([rot_env, rot_core, 0.0, 0.0, 0.01, 0.0, 0.0, 0.0, 1.0, 0.0])
+    width = np.array([numax, numax, 1.5, 0.15, 0.8 * numax, 2.5])          # nu_max, nu_dip, alpha, Gamma_alpha, W_dip, DeltaGamma_dip
+    noise = np.array([30.0, 40.0, 2.0, 10.0, 8.0, 2.0, 0.4])
+    cfg = np.array([trunc_c, 0.0, 0.0, float(model_type), float(bias_type), float(nferr)])
+    params = np.concatenate([heights, vis, fl0, l1, fl2, fl3, split, width, noise, [inclination], cfg])
+    plength = np.array([nmax, 3, nmax, l1.size, fl2.size, fl3.size, 10, 6, 7, 1, 6], dtype=np.int32)
+    assert params.size == plength.sum()
+    return params, plength

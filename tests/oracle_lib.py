@@ -85,6 +85,30 @@ def load(fast=False):
     lib.orc_apply_generic_priors.argtypes = [c_dp, C.c_long, C.c_long, c_dp, C.c_long, c_ip]
     lib.orc_call_prior.restype = C.c_double
     lib.orc_call_prior.argtypes = [C.c_int, c_dp, c_ip, c_dp, c_ip, c_dp]
+    # red-giant model and pre-step (armm_oracle.c)
+    class EigenSols(C.Structure):
+        _fields_ = [("n_m", C.c_long), ("n_p", C.c_long), ("n_g", C.c_long), ("nu_m", c_dp), ("nu_p", c_dp), ("nu_g", c_dp),
+                    ("dnup", c_dp), ("dPg", c_dp)]
+
+    class RgbModes(C.Structure):
+        _fields_ = [("N0", C.c_long), ("N1", C.c_long), ("fl0", c_dp), ("Wl0", c_dp), ("Hl0", c_dp), ("fl1", c_dp), ("Wl1", c_dp),
+                    ("Hl1", c_dp), ("a1_l1", c_dp), ("ksi", c_dp), ("g", C.c_double * 6)]
+
+    lib.EigenSols, lib.RgbModes = EigenSols, RgbModes
+    lib.orc_eigensols_free.restype = None
+    lib.orc_eigensols_free.argtypes = [C.POINTER(EigenSols)]
+    lib.orc_armm_solve_O2p.restype = C.c_int
+    lib.orc_armm_solve_O2p.argtypes = [C.c_double, C.c_double, C.c_int] + [C.c_double] * 9 + [C.POINTER(EigenSols)]
+    lib.orc_armm_solve_O2from_l0.restype = C.c_int
+    lib.orc_armm_solve_O2from_l0.argtypes = [c_dp, C.c_long, C.c_int] + [C.c_double] * 7 + [C.POINTER(EigenSols)]
+    lib.orc_ksi_fct2_precise.restype = None
+    lib.orc_ksi_fct2_precise.argtypes = [c_dp, C.c_long, c_dp, c_dp, C.c_long, c_dp, c_dp, C.c_long, C.c_double, c_dp]
+    lib.orc_spline_eval.restype = C.c_double
+    lib.orc_spline_eval.argtypes = [c_dp, c_dp, C.c_long, C.c_int, C.c_double]
+    lib.orc_rgb_v4_modes.restype = C.c_int
+    lib.orc_rgb_v4_modes.argtypes = [c_dp, c_ip, C.c_double, C.POINTER(RgbModes)]
+    lib.orc_rgb_modes_free.restype = None
+    lib.orc_rgb_modes_free.argtypes = [C.POINTER(RgbModes)]
     return lib
 
 
@@ -93,6 +117,47 @@ class Oracle:
 
     def __init__(self, fast=False):
         self.lib = load(fast)
+
+    # ---- red-giant pre-step (armm_oracle.c) ----
+    def _sols(self, e):
+        take = lambda p, n: np.array([p[i] for i in range(n)])
+        out = dict(nu_m=take(e.nu_m, e.n_m), nu_p=take(e.nu_p, e.n_p), nu_g=take(e.nu_g, e.n_g), dnup=take(e.dnup, e.n_p),
+                   dPg=take(e.dPg, e.n_g))
+        self.lib.orc_eigensols_free(C.byref(e))
+        return out
+
+    def armm_solve_O2p(self, Dnu_p, epsilon, el, delta0l, alpha_p, nmax, DPl, alpha, q, fmin, fmax, resol):
+        e = self.lib.EigenSols()
+        rc = self.lib.orc_armm_solve_O2p(Dnu_p, epsilon, el, delta0l, alpha_p, nmax, DPl, alpha, q, fmin, fmax, resol, C.byref(e))
+        return rc, (self._sols(e) if rc == 0 else None)
+
+    def armm_solve_O2from_l0(self, nu_l0, el, delta0l, DPl, alpha, q, resol, fmin, fmax):
+        e = self.lib.EigenSols()
+        v = np.ascontiguousarray(nu_l0, dtype=np.float64)
+        rc = self.lib.orc_armm_solve_O2from_l0(_dp(v), v.size, el, delta0l, DPl, alpha, q, resol, fmin, fmax, C.byref(e))
+        return rc, (self._sols(e) if rc == 0 else None)
+
+    def ksi_precise(self, nu, nu_p, dnup, nu_g, dPg, q):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (nu, nu_p, dnup, nu_g, dPg)]
+        out = np.zeros(a[0].size)
+        self.lib.orc_ksi_fct2_precise(_dp(a[0]), a[0].size, _dp(a[1]), _dp(a[2]), a[1].size, _dp(a[3]), _dp(a[4]), a[3].size, q, _dp(out))
+        return out
+
+    def spline_eval(self, xn, yn, kind, x):
+        xn, yn = np.ascontiguousarray(xn, dtype=np.float64), np.ascontiguousarray(yn, dtype=np.float64)
+        return np.array([self.lib.orc_spline_eval(_dp(xn), _dp(yn), xn.size, kind, float(v)) for v in np.atleast_1d(x)])
+
+    def rgb_modes(self, params, plength, step):
+        p, pl = np.ascontiguousarray(params, dtype=np.float64), np.ascontiguousarray(plength, dtype=np.int32)
+        m = self.lib.RgbModes()
+        rc = self.lib.orc_rgb_v4_modes(_dp(p), _ip(pl), float(step), C.byref(m))
+        if rc != 0:
+            return rc, None
+        take = lambda q, n: np.array([q[i] for i in range(n)])
+        out = dict(fl0=take(m.fl0, m.N0), Wl0=take(m.Wl0, m.N0), Hl0=take(m.Hl0, m.N0), fl1=take(m.fl1, m.N1), Wl1=take(m.Wl1, m.N1),
+                   Hl1=take(m.Hl1, m.N1), a1_l1=take(m.a1_l1, m.N1), ksi=take(m.ksi, m.N1), g=np.array(list(m.g)))
+        self.lib.orc_rgb_modes_free(C.byref(m))
+        return rc, out
 
     def amplitude_ratio(self, l, inc_deg):
         v = np.zeros(2 * l + 1)
