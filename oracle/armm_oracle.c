@@ -142,14 +142,15 @@ int orc_armm_solve_O2p(double Dnu_p, double epsilon, int el, double delta0l, dou
     np_max = (int)ceil(np_max + alpha_p * pow(np_max - nmax, 2) / 2.);
     int ng_min = (int)floor(1e6 / (fmax * DPl) - alpha);
     int ng_max = (int)ceil(1e6 / (fmin * DPl) - alpha);
-    if (ng_min <= 0 && ng_max < 1) return ORC_ERR_BAD_ARG;  /* "impossible star": the reference returns an empty structure */
+    if (ng_min <= 0 && ng_max < 1) return ORC_OK;  /* "impossible star": the reference returns an EMPTY structure and carries on */
     if (ng_min <= 0 && ng_max >= 1) ng_min = 1;
     const double zone = (ng_max - ng_min < 6) ? (double)np_max : 1.75;
     if (np_min <= 0) np_min = 1;
     if (fmin <= 150) fact = 0.01;
     if (fmin <= 50) fact = 0.005;
     const long Lp = np_max - np_min, Lg = ng_max - ng_min;
-    if (Lp < 1 || Lg < 1) return ORC_ERR_BAD_ARG;
+    if (Lg < 1) return ORC_OK;  /* no g mode in range: nothing to couple with (empty set) */
+    if (Lp < 1) return ORC_ERR_BAD_ARG;
     out->nu_p = dalloc(Lp); out->nu_g = dalloc(Lg); out->dnup = dalloc(Lp); out->dPg = dalloc(Lg);
     out->n_p = Lp; out->n_g = Lg;
     double *loc = dalloc(Lp);
@@ -181,7 +182,7 @@ int orc_armm_solve_O2from_l0(const double *nu_l0, long n0, int el, double delta0
     if (fmin < 0) fmin = 0;
     int ng_min = (int)floor(1e6 / (fmax * DPl) - alpha);
     int ng_max = (int)ceil(1e6 / (fmin * DPl) - alpha);
-    if (ng_min <= 0 && ng_max < 1) return ORC_ERR_BAD_ARG;
+    if (ng_min <= 0 && ng_max < 1) return ORC_OK;  /* empty structure, as above */
     if (ng_min <= 0 && ng_max >= 1) ng_min = 1;
     const double zone = (ng_max - ng_min < 6) ? 20. : 1.75;
     if (fmin <= 150) fact = 0.01;
@@ -200,7 +201,8 @@ int orc_armm_solve_O2from_l0(const double *nu_l0, long n0, int el, double delta0
     }
     free(ext);
     const long Lg = ng_max - ng_min;
-    if (Lp < 2 || Lg < 1) { orc_eigensols_free(out); return ORC_ERR_BAD_ARG; }
+    if (Lg < 1) { orc_eigensols_free(out); return ORC_OK; }
+    if (Lp < 2) { orc_eigensols_free(out); return ORC_ERR_BAD_ARG; }
     out->n_p = Lp; out->n_g = Lg;
     out->nu_g = dalloc(Lg); out->dnup = dalloc(Lp); out->dPg = dalloc(Lg);
     for (int ng = ng_min; ng < ng_max; ng++) out->nu_g[ng - ng_min] = (double)(1e6L / ((ng + (long double)alpha) * DPl));

@@ -12,6 +12,7 @@
 
 #include "../../include/tamcmc_hip.h"
 #include "kernels.h"
+#include "rgb_prestep.h"
 #include "mode_tables.h"
 
 #include "ctx.h"
@@ -248,7 +249,10 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, cons
     int per = 0, stride = 1, first_err = TAMCMC_OK;
     std::vector<int32_t> st_local;
     if (!status) { st_local.resize((size_t)B); status = st_local.data(); }
-    int rc = stage_params(c, model_id, B, params, Nparams, plength, status, &per, &stride, &first_err);
+    // the red-giant model needs its device pre-step (mixed-mode solver, zeta) before the rows can be written
+    int rc = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID)
+                 ? tamcmc::rgb_stage_params(c, B, params, Nparams, plength, status, &per, &stride, &first_err)
+                 : stage_params(c, model_id, B, params, Nparams, plength, status, &per, &stride, &first_err);
     if (rc) return rc;
     rc = run_staged(c, B, StageLayout(B, stride, (size_t)B * per), stride, Tcoefs, p, logL, model);
     if (rc) return rc;

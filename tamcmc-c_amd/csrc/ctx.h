@@ -74,6 +74,7 @@ struct tamcmc_hip_ctx {
     tamcmc::PinBuf<unsigned char> h_stage;
     tamcmc::DevBuf<unsigned char> d_stage;
     tamcmc::DevBuf<double> d_part, d_S, d_model;
+    tamcmc::DevBuf<unsigned char> d_rgb;  // red-giant pre-step workspace (rgb_prestep.hip)
     tamcmc::DevBuf<double> d_bg;  // FAST far field: background series per (evaluation, tile) (bg_series.h)
     // finite-difference batches built on the device (fd_batch.hip)
     tamcmc::DevBuf<unsigned char> d_fd, d_poly;

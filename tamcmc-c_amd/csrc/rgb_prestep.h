@@ -1,0 +1,13 @@
+// rgb_prestep.h -- red-giant model (id 25) table builder with its device pre-step (rgb_prestep.hip).
+#pragma once
+#include <cstdint>
+
+#include "ctx.h"
+
+#define TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID 25
+
+namespace tamcmc {
+// Fills c->h_stage with the B variable-length tables (layout StageLayout(B, stride, B*per)); status[b] per vector.
+int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Nparams, const int32_t *plength, int32_t *status,
+                     int *per_out, int *stride_out, int *first_err);
+}  // namespace tamcmc

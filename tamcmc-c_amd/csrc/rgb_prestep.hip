@@ -1,0 +1,552 @@
+// rgb_prestep.hip -- red-giant model model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (id 25, tamcmc/sources/models.cpp:4684-5079):
+// the per-proposal pre-step that turns a parameter vector into a VARIABLE-LENGTH multiplet table for k_loglike.
+//
+//   host   : scalar unpack (width law, l=0 heights, linear fit of the l=0 ladder, p / g asymptotic ladders)      models.cpp:4755-4866
+//   device : ARMM mixed-mode solver -- scan p(nu)-g(nu) on the resol grid for sign changes, refine each on the
+//            fine local grid by inverse linear interpolation, keep true intersections        external/ARMM/solver_mm.cpp:340-443
+//            one workgroup per (parameter vector, p mode); sort + tolerance-unique per vector                     :586-593
+//   host   : + spline bias of the frequencies (cubic / Hermite, natural ends)            external/spline/src/spline.h:242-498
+//   device : zeta function at the mixed modes and its normalisation, max over a 4-year-resolution grid of the
+//            sum over all (p, g) pairs                                                  external/ARMM/bump_DP.cpp:46-78, :125-188
+//   host   : mixed-mode heights / widths / rotational splittings, windows, table rows    bump_DP.cpp:203-254, :531-547; models.cpp:4867-5000
+//
+// The reference runs the solver for every (p mode, g mode) pair whose g mode lies within the search zone of the p mode.  g(nu)
+// depends on nu_g only through tan(pi 1e6 (1/nu - 1/nu_g)/DPl), which is the same function for every g mode of the ladder
+// (1e6/(nu_g DPl) = n_g + alpha), so all those pairs return the same roots up to rounding and the duplicates are removed
+// afterwards; here each p mode is solved ONCE, against the first g mode inside its zone (~40x less work, same roots to ~1e-12).
+// Behaviour kept from the reference: a root closer than 2*resol to a pole of tan() is lost (its refinement window holds the
+// pole, the interpolation extrapolates and the 0.1 % ratio test rejects it) -- tests/test_oracle_rgb.py documents it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ctx.h"
+#include "mode_tables.h"
+#include "mode_tables_impl.h"
+#include "rgb_prestep.h"
+#include "kernels.h"
+
+namespace tamcmc {
+const mt::PolyTab &poly_table();  // mode_tables.cpp
+namespace rgb {
+
+constexpr int MAXP = 32;      // p modes per vector (fmax-fmin+2 Dnu)/Dnu + margins
+constexpr int MAXSOL = 1024;  // mixed modes per vector before de-duplication
+constexpr int WG = 256;
+
+struct Prep {  // one parameter vector's solver inputs
+    int Lp, Lg, ng_min, status;
+    int ig0[MAXP];                 // first g mode inside the zone of p mode ip, -1: none (the reference skips the pair)
+    double nu_p[MAXP], dnu_loc[MAXP], dnup[MAXP];
+    double Dnu_p, DPl, alpha, q, zone, resol, fact, keep_lo, keep_hi;
+};
+
+__host__ __device__ inline double nu_g_of(const Prep &p, int ig) { return 1e6 / (((double)(p.ng_min + ig) + p.alpha) * p.DPl); }
+
+namespace {
+
+__device__ __forceinline__ double f_pg(double nu, double nu_p, double nu_g, double Dnu, double DPl, double q) {
+    const double PI = 3.141592653589793238;
+    const double X = PI * (1. / nu - 1. / nu_g) * 1e6 / DPl;
+    return (nu - nu_p) - Dnu * atan(q * tan(X)) / PI;
+}
+__device__ __forceinline__ bool changes_sign(double a, double b) {  // sign_change(), solver_mm.cpp:82-121
+    return ((b >= 0 && a < 0) || (b > 0 && a <= 0)) || (b <= 0 && a >= 0);
+}
+
+// One workgroup per (vector b, p mode ip).
+__global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sols, int *nsol) {
+    const int b = blockIdx.y, ip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Prep &P = preps[b];
+    if (ip >= P.Lp || P.status != 0 || P.ig0[ip] < 0) return;
+    const double nu_p = P.nu_p[ip], Dl = P.dnu_loc[ip], nu_g = nu_g_of(P, P.ig0[ip]);
+    const double numin = nu_p - P.zone * P.Dnu_p, numax = nu_p + P.zone * P.Dnu_p;
+    long n;
+    double lo;
+    if (numin >= 0) { n = (long)((numax - numin) / P.resol); lo = numin; }
+    else { n = (long)(numax / P.resol); lo = 0; }
+    if (n < 2) return;
+    const double step = (numax - lo) / (double)(n - 1);
+    auto grid = [&](long i) { return (i == n - 1) ? numax : lo + (double)i * step; };
+    __shared__ long s_cand[512];
+    __shared__ int s_nc;
+    if (tid == 0) s_nc = 0;
+    __syncthreads();
+    // ---- scan: candidate = index i with a sign change between grid points i and i+1
+    for (long i0 = 0; i0 < n - 1; i0 += WG) {
+        const long i = i0 + tid;
+        if (i < n - 1) {
+            const double fa = f_pg(grid(i), nu_p, nu_g, Dl, P.DPl, P.q), fb = f_pg(grid(i + 1), nu_p, nu_g, Dl, P.DPl, P.q);
+            if (changes_sign(fa, fb)) {
+                const int k = atomicAdd(&s_nc, 1);
+                if (k < 512) s_cand[k] = i;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_nc > 512) {  // more sign changes than the candidate list holds: flag the vector (the host reports it), do not guess
+        if (tid == 0) atomicAdd(&nsol[b], 2 * MAXSOL);
+        return;
+    }
+    const int nc = s_nc;
+    // ---- refine: one wave per candidate (solver_mm.cpp:378-406 + lin_interpol of interpol.cpp with x = p-g, y = nu)
+    for (int c = wave; c < nc; c += WG / 64) {
+        const double x0 = grid(s_cand[c]);
+        const double rmin = x0 - 2 * P.resol, rmax = x0 + 2 * P.resol;
+        const long nl = (long)((rmax - rmin) / (P.resol * P.fact));
+        if (nl < 2) continue;
+        const double ls = (rmax - rmin) / (double)(nl - 1);
+        auto lg = [&](long j) { return (j == nl - 1) ? rmax : rmin + (double)j * ls; };
+        auto fl = [&](long j) { return f_pg(lg(j), nu_p, nu_g, Dl, P.DPl, P.q); };
+        const double f_first = fl(0), f_last = fl(nl - 1);
+        // first j with f[j] <= 0 <= f[j+1]
+        long best = nl;
+        for (long j0 = 0; j0 < nl - 1; j0 += 64) {
+            const long j = j0 + lane;
+            bool hit = false;
+            if (j < nl - 1) {
+                const double fa = fl(j), fb = fl(j + 1);
+                hit = !(0.0 < fa || 0.0 > fb);  // the loop condition of lin_interpol, negated
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) { best = j0 + (long)(__ffsll((long long)m) - 1); break; }
+        }
+        if (lane == 0) {
+            double a = 0, bb = 0;
+            if (0.0 >= f_first && 0.0 <= f_last) {
+                const long j = best < nl - 1 ? best : nl - 2;
+                const double fa = fl(j), fb = fl(j + 1);
+                a = (lg(j + 1) - lg(j)) / (fb - fa);
+                bb = lg(j) - a * fa;
+            }
+            if (0.0 < f_first) {
+                a = (lg(1) - lg(0)) / (fl(1) - f_first);
+                bb = lg(0) - a * f_first;
+            }
+            if (0.0 > f_last) {
+                const double fa = fl(nl - 2);
+                a = (lg(nl - 1) - lg(nl - 2)) / (f_last - fa);
+                bb = lg(nl - 2) - a * fa;
+            }
+            const double prop = a * 0.0 + bb;
+            const double PI = 3.141592653589793238;
+            const double X = PI * (1. / prop - 1. / nu_g) * 1e6 / P.DPl;
+            const double ratio = (Dl * atan(P.q * tan(X)) / PI) / (prop - nu_p);
+            if (ratio >= 0.999 && ratio <= 1.001 && prop >= P.keep_lo && prop <= P.keep_hi) {
+                const int k = atomicAdd(&nsol[b], 1);
+                if (k < MAXSOL) sols[(size_t)b * MAXSOL + k] = prop;
+            }
+        }
+    }
+}
+
+// One workgroup per vector: bitonic sort of its solutions, then std::unique with |a-b| <= 2 resol (solver_mm.cpp:586-593).
+__global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, double *sols, int *nsol) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ double s[MAXSOL];
+    if (nsol[b] > MAXSOL) return;  // overflow flag: left for the host
+    const int n = nsol[b];
+    for (int i = tid; i < MAXSOL; i += WG) s[i] = i < n ? sols[(size_t)b * MAXSOL + i] : INFINITY;
+    __syncthreads();
+    for (int k = 2; k <= MAXSOL; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < MAXSOL; i += WG) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const double a = s[i], c = s[l];
+                    if ((a > c) == up) { s[i] = c; s[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {
+        const double tol = 2 * preps[b].resol;
+        int m = 0;
+        for (int i = 0; i < n; i++)
+            if (m == 0 || !(fabs(sols[(size_t)b * MAXSOL + m - 1] - s[i]) <= tol)) sols[(size_t)b * MAXSOL + m++] = s[i];
+        nsol[b] = m;
+    }
+}
+
+__device__ __forceinline__ double ksi_one(double nu, double nu_p, double nu_g, double Dnu_p, double DPl, double q) {  // bump_DP.cpp:46-78
+    const double PI = 3.14159265358979323846;
+    const double up = PI * 1e6 * (1. / nu - 1. / nu_g) / DPl;
+    const double down = PI * (nu - nu_p) / Dnu_p;
+    const double front = 1e-6 * nu * nu * DPl / (q * Dnu_p);
+    const double cu = cos(up), cd = cos(down);
+    return 1. / (1. + front * ((cu * cu) / (cd * cd)));
+}
+__device__ __forceinline__ double ksi_sum(const Prep &P, double nu) {  // sum over all (p, g) pairs, the reference's order
+    double s = 0;
+    for (int ip = 0; ip < P.Lp; ip++) {
+        double loc = 0;
+        for (int ig = 0; ig < P.Lg; ig++) loc += ksi_one(nu, P.nu_p[ip], nu_g_of(P, ig), P.dnup[ip], P.DPl, P.q);
+        s += loc;
+    }
+    return s;
+}
+
+// grid (chunks, B): un-normalised zeta at the vector's modes (chunk 0) and the maximum of the same sum over the high-resolution grid
+__global__ void __launch_bounds__(WG) k_zeta(const Prep *preps, const double *fl1, const int *n1, double *ksi, unsigned long long *norm_bits,
+                                             int chunks) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const Prep &P = preps[b];
+    if (P.status != 0 || P.Lp < 1 || P.Lg < 1) return;  // failed vector, or no g mode in range (no mixed modes)
+    if (blockIdx.x == 0)
+        for (int i = tid; i < n1[b]; i += WG) ksi[(size_t)b * MAXSOL + i] = ksi_sum(P, fl1[(size_t)b * MAXSOL + i]);
+    double pmin = P.nu_p[0], pmax = P.nu_p[0];
+    for (int i = 1; i < P.Lp; i++) { pmin = fmin(pmin, P.nu_p[i]); pmax = fmax(pmax, P.nu_p[i]); }
+    const double gmax = nu_g_of(P, 0), gmin = nu_g_of(P, P.Lg - 1);  // the g ladder decreases with n_g
+    const double lo = pmin >= gmin ? gmin : pmin, hi = pmax >= gmax ? pmax : gmax;
+    const double resol = 1e6 / (4 * 365. * 86400.);
+    const long nh = (long)((hi - lo) / resol);
+    double best = 0;
+    if (nh >= 2) {
+        const double step = (hi - lo) / (double)(nh - 1);
+        for (long i = (long)blockIdx.x * WG + tid; i < nh; i += (long)chunks * WG) {
+            const double v = ksi_sum(P, (i == nh - 1) ? hi : lo + (double)i * step);
+            if (v > best) best = v;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) best = fmax(best, __shfl_down(best, off, 64));
+    if ((tid & 63) == 0 && best > 0) atomicMax(&norm_bits[b], (unsigned long long)__double_as_longlong(best));  // positive doubles order as integers
+}
+
+// ---------------------------------------------------------------- host side
+struct Spline {  // natural cubic (type 1) or cubic Hermite (type 2) through the bias nodes, spline.h:242-498
+    std::vector<double> x, y, b, c, d;
+    double c0 = 0;
+    bool set(const double *xn, const double *yn, int n, int type) {
+        if (n < 3) return false;
+        for (int i = 0; i < n - 1; i++)
+            if (!(xn[i] < xn[i + 1])) return false;
+        x.assign(xn, xn + n); y.assign(yn, yn + n); b.assign((size_t)n, 0); c.assign((size_t)n, 0); d.assign((size_t)n, 0);
+        if (type == 1) {
+            std::vector<double> sub((size_t)n, 0), dia((size_t)n, 2.0), sup((size_t)n, 0), rhs((size_t)n, 0);
+            for (int i = 1; i < n - 1; i++) {
+                sub[(size_t)i] = (x[(size_t)i] - x[(size_t)i - 1]) / 3.0;
+                dia[(size_t)i] = 2.0 / 3.0 * (x[(size_t)i + 1] - x[(size_t)i - 1]);
+                sup[(size_t)i] = (x[(size_t)i + 1] - x[(size_t)i]) / 3.0;
+                rhs[(size_t)i] = (y[(size_t)i + 1] - y[(size_t)i]) / (x[(size_t)i + 1] - x[(size_t)i]) -
+                                 (y[(size_t)i] - y[(size_t)i - 1]) / (x[(size_t)i] - x[(size_t)i - 1]);
+            }
+            for (int i = 1; i < n; i++) {
+                const double w = sub[(size_t)i] / dia[(size_t)i - 1];
+                dia[(size_t)i] -= w * sup[(size_t)i - 1];
+                rhs[(size_t)i] -= w * rhs[(size_t)i - 1];
+            }
+            c[(size_t)n - 1] = rhs[(size_t)n - 1] / dia[(size_t)n - 1];
+            for (int i = n - 2; i >= 0; i--) c[(size_t)i] = (rhs[(size_t)i] - sup[(size_t)i] * c[(size_t)i + 1]) / dia[(size_t)i];
+            for (int i = 0; i < n - 1; i++) {
+                const double h = x[(size_t)i + 1] - x[(size_t)i];
+                d[(size_t)i] = (c[(size_t)i + 1] - c[(size_t)i]) / (3.0 * h);
+                b[(size_t)i] = (y[(size_t)i + 1] - y[(size_t)i]) / h - (2.0 * c[(size_t)i] + c[(size_t)i + 1]) * h / 3.0;
+            }
+            const double h = x[(size_t)n - 1] - x[(size_t)n - 2];
+            b[(size_t)n - 1] = 3.0 * d[(size_t)n - 2] * h * h + 2.0 * c[(size_t)n - 2] * h + b[(size_t)n - 2];
+        } else {
+            for (int i = 1; i < n - 1; i++) {
+                const double h = x[(size_t)i + 1] - x[(size_t)i], hl = x[(size_t)i] - x[(size_t)i - 1];
+                b[(size_t)i] = -h / (hl * (hl + h)) * y[(size_t)i - 1] + (h - hl) / (hl * h) * y[(size_t)i] + hl / (h * (hl + h)) * y[(size_t)i + 1];
+            }
+            b[0] = 0.5 * (-b[1] + 3.0 * (y[1] - y[0]) / (x[1] - x[0]));
+            b[(size_t)n - 1] = 0.5 * (-b[(size_t)n - 2] + 3.0 * (y[(size_t)n - 1] - y[(size_t)n - 2]) / (x[(size_t)n - 1] - x[(size_t)n - 2]));
+            for (int i = 0; i < n - 1; i++) {
+                const double h = x[(size_t)i + 1] - x[(size_t)i];
+                c[(size_t)i] = (3.0 * (y[(size_t)i + 1] - y[(size_t)i]) / h - (2.0 * b[(size_t)i] + b[(size_t)i + 1])) / h;
+                d[(size_t)i] = ((b[(size_t)i + 1] - b[(size_t)i]) / (3.0 * h) - 2.0 / 3.0 * c[(size_t)i]) / h;
+            }
+        }
+        c0 = c[0];
+        return true;
+    }
+    double operator()(double v) const {
+        const size_t n = x.size();
+        size_t idx = 0;
+        while (idx + 1 < n && x[idx + 1] <= v) idx++;
+        const double h = v - x[idx];
+        if (v < x[0]) return (c0 * h + b[0]) * h + y[0];
+        if (v > x[n - 1]) return (c[n - 1] * h + b[n - 1]) * h + y[n - 1];
+        return ((d[idx] * h + c[idx]) * h + b[idx]) * h + y[idx];
+    }
+};
+
+struct Unpacked {  // host scalars of one vector
+    int Nmax, lmax, Nfl0, Nfl1, Nfl2, Nfl3, Nnoise, onoise, ocfg, os, o1;
+    bool do_amp;
+    double g[6], trunc_c, model_type, bias_type, Hfactor, Wfactor, rot_env, rot_core, inclination, Vl[4], eta0, asym;
+    int Nferr;
+    std::vector<double> Wl0, Hl0;
+    double fmin, fmax;
+};
+
+double app_width(const double g[6], double f) {  // models.cpp:4788-4794
+    const double lnGamma0 = g[2] * std::log(f / g[0]) + std::log(g[3]);
+    const double e = 2. * std::log(f / g[1]) / std::log(g[4] / g[0]);
+    return std::exp(lnGamma0 + -std::log(g[5]) / (1. + std::pow(e, 2)));
+}
+
+// models.cpp:4727-4866 + solver_mm.cpp:470-555 / :624-705 (everything before the pair loop)
+int unpack(const double *p, const int32_t *pl, double step, Unpacked &u, Prep &P) {
+    const long double pi = M_PI;
+    std::memset(&P, 0, sizeof P);
+    u.Nmax = pl[0]; u.lmax = pl[1]; u.Nfl0 = pl[2]; u.Nfl1 = pl[3]; u.Nfl2 = pl[4]; u.Nfl3 = pl[5];
+    const int Nsplit = pl[6], Nwidth = pl[7], Ninc = pl[9];
+    u.Nnoise = pl[8];
+    const int Nf = u.Nfl0 + u.Nfl1 + u.Nfl2 + u.Nfl3;
+    u.os = u.Nmax + u.lmax + Nf;
+    u.onoise = u.os + Nsplit + Nwidth;
+    u.ocfg = u.onoise + u.Nnoise + Ninc;
+    u.o1 = u.Nmax + u.lmax + u.Nfl0;
+    u.trunc_c = p[u.ocfg];
+    u.do_amp = p[u.ocfg + 1] != 0;
+    u.model_type = p[u.ocfg + 3];
+    u.bias_type = p[u.ocfg + 4];
+    u.Nferr = (int)p[u.ocfg + 5];
+    if (u.Nmax < 2 || u.Nmax != u.Nfl0 || u.Nferr < 0 || u.Nfl1 != 8 + 2 * u.Nferr || Nwidth < 6 || Nsplit < 10 || u.lmax > 3) return TAMCMC_ERR_BAD_ARG;
+    for (int k = 0; k < 6; k++) u.g[k] = std::fabs(p[u.os + Nsplit + k]);
+    const double *fl0 = p + u.Nmax + u.lmax;
+    u.Wl0.resize((size_t)u.Nmax); u.Hl0.resize((size_t)u.Nmax);
+    for (int n = 0; n < u.Nmax; n++) u.Wl0[(size_t)n] = app_width(u.g, fl0[n]);
+    for (int n = 0; n < u.Nmax; n++)
+        u.Hl0[(size_t)n] = u.do_amp ? (double)fabsl(p[n] * (1. / u.Wl0[(size_t)n] / pi)) : std::fabs(p[n]);
+    const double delta0l = p[u.o1], DPl = std::fabs(p[u.o1 + 1]), alpha_g = std::fabs(p[u.o1 + 2]), q = std::fabs(p[u.o1 + 3]);
+    u.Wfactor = std::fabs(p[u.o1 + 6]); u.Hfactor = std::fabs(p[u.o1 + 7]);
+    u.rot_env = std::fabs(p[u.os]); u.rot_core = std::fabs(p[u.os + 1]);
+    u.asym = p[u.os + 9];
+    u.inclination = std::fabs(p[u.onoise + u.Nnoise]);
+    u.Vl[0] = 1;
+    for (int l = 1; l <= 3; l++) u.Vl[l] = l <= u.lmax ? std::fabs(p[u.Nmax + l - 1]) : 0.0;
+    u.eta0 = (p[u.os + 8] == 1) ? mt::eta0_fct(fl0, u.Nfl0) : 0.0;
+    u.fmin = *std::min_element(fl0, fl0 + u.Nfl0);
+    u.fmax = *std::max_element(fl0, fl0 + u.Nfl0);
+    double fit[2];
+    mt::linfit_index(fl0, u.Nfl0, fit);
+    const double Dnu_p = fit[0];
+    if (!(Dnu_p > 0) || u.fmin - Dnu_p < 0) return TAMCMC_ERR_BAD_ARG;  // the reference exits (models.cpp:4851-4857)
+    P.Dnu_p = Dnu_p; P.DPl = DPl; P.alpha = alpha_g; P.q = q; P.resol = step; P.fact = 0.04;
+    double fmin_s, fmax_s;
+    if (u.model_type == 0) {  // solve_mm_asymptotic_O2p(Dnu_p, eps, 1, delta0l, 0, 0, ...), fmin - Dnu .. fmax + Dnu
+        const int n0 = (int)std::floor(fit[1] / Dnu_p);
+        const double eps = fit[1] / Dnu_p - n0;
+        fmin_s = u.fmin - Dnu_p; fmax_s = u.fmax + Dnu_p;
+        const int el = 1;
+        int np_min = (int)std::floor(fmin_s / Dnu_p - eps - el / 2 - delta0l);  // el/2: integer division, as in the reference
+        int np_max = (int)std::ceil(fmax_s / Dnu_p - eps - el / 2 - delta0l);
+        int ng_min = (int)std::floor(1e6 / (fmax_s * DPl) - alpha_g), ng_max = (int)std::ceil(1e6 / (fmin_s * DPl) - alpha_g);
+        if (ng_min <= 0 && ng_max < 1) { P.Lp = 0; return TAMCMC_OK; }  // "impossible star": no mixed modes, the model carries on (solver_mm.cpp:497-501)
+        if (ng_min <= 0 && ng_max >= 1) ng_min = 1;
+        P.zone = (ng_max - ng_min < 6) ? (double)np_max : 1.75;
+        if (np_min <= 0) np_min = 1;
+        P.Lp = np_max - np_min; P.Lg = ng_max - ng_min; P.ng_min = ng_min;
+        if (P.Lg < 1) { P.Lp = 0; return TAMCMC_OK; }  // no g mode in range
+        if (P.Lp < 1 || P.Lp > MAXP) return TAMCMC_ERR_BAD_ARG;
+        for (int np = np_min; np < np_max; np++) {
+            P.nu_p[np - np_min] = (double)((np + (long double)eps + el / 2.L + delta0l) * Dnu_p);
+            P.dnu_loc[np - np_min] = Dnu_p;  // alpha_p = 0
+        }
+        P.keep_lo = fmin_s; P.keep_hi = fmax_s;
+    } else {  // solve_mm_asymptotic_O2from_l0(fl0, 1, delta0l, ...): the l=0 ladder shifted, three extra orders on each side
+        fmin_s = u.fmin - Dnu_p; fmax_s = u.fmax + Dnu_p;
+        if (fmin_s < 0) fmin_s = 0;
+        int ng_min = (int)std::floor(1e6 / (fmax_s * DPl) - alpha_g), ng_max = (int)std::ceil(1e6 / (fmin_s * DPl) - alpha_g);
+        if (ng_min <= 0 && ng_max < 1) { P.Lp = 0; return TAMCMC_OK; }
+        if (ng_min <= 0 && ng_max >= 1) ng_min = 1;
+        P.zone = (ng_max - ng_min < 6) ? 20. : 1.75;
+        std::vector<double> ext;
+        ext.push_back(u.fmin - 3 * Dnu_p); ext.push_back(u.fmin - 2 * Dnu_p); ext.push_back(u.fmin - Dnu_p);
+        for (int k = 0; k < u.Nfl0; k++) ext.push_back(fl0[k]);
+        ext.push_back(u.fmax + Dnu_p); ext.push_back(u.fmax + 2 * Dnu_p); ext.push_back(u.fmax + 3 * Dnu_p);
+        int Lp = 0;
+        for (double e : ext) {
+            const double v = e + (double)(1 / 2.L * Dnu_p + delta0l);
+            if (v >= fmin_s && v <= fmax_s) {
+                if (Lp >= MAXP) return TAMCMC_ERR_BAD_ARG;
+                P.nu_p[Lp++] = v;
+            }
+        }
+        P.Lp = Lp; P.Lg = ng_max - ng_min; P.ng_min = ng_min;
+        if (P.Lg < 1) { P.Lp = 0; return TAMCMC_OK; }
+        if (P.Lp < 2) return TAMCMC_ERR_BAD_ARG;
+        P.keep_lo = u.fmin; P.keep_hi = u.fmax;
+    }
+    if (fmin_s <= 150) P.fact = 0.01;
+    if (fmin_s <= 50) P.fact = 0.005;
+    // first derivative of the p ladder on the index grid (derivatives_handler.cpp:425-457)
+    for (int i = 0; i < P.Lp; i++) {
+        if (P.Lp == 1) P.dnup[i] = 0;
+        else if (i == 0) P.dnup[i] = P.nu_p[1] - P.nu_p[0];
+        else if (i == P.Lp - 1) P.dnup[i] = P.nu_p[i] - P.nu_p[i - 1];
+        else P.dnup[i] = (P.nu_p[i + 1] - P.nu_p[i - 1]) / 2.;
+    }
+    if (u.model_type != 0)
+        for (int i = 0; i < P.Lp; i++) P.dnu_loc[i] = P.dnup[i];  // the from-l0 driver hands the local derivative to the solver (:717)
+    for (int ip = 0; ip < P.Lp; ip++) {
+        P.ig0[ip] = -1;
+        const double lo = P.nu_p[ip] - P.zone * Dnu_p, hi = P.nu_p[ip] + P.zone * Dnu_p;
+        for (int ig = 0; ig < P.Lg; ig++) {
+            const double g = nu_g_of(P, ig);
+            if (g >= lo && g <= hi) { P.ig0[ip] = ig; break; }
+        }
+    }
+    return TAMCMC_OK;
+}
+
+}  // namespace
+}  // namespace rgb
+
+// Builds the B tables of model 25 straight into the pinned staging block (same layout as capi.hip's stage_params).
+int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Nparams, const int32_t *plength, int32_t *status,
+                     int *per_out, int *stride_out, int *first_err) {
+    using namespace rgb;
+    const double *hx = c->hx.data();
+    const int64_t Nx = c->Nx;
+    const double step = hx[2] - hx[1];  // models.cpp:4719
+    const int stride = plength[8] > 0 ? plength[8] : 1;
+    if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
+    std::vector<Unpacked> U((size_t)B);
+    std::vector<Prep> P((size_t)B);
+    for (int b = 0; b < B; b++) {
+        status[b] = unpack(params + (size_t)b * Nparams, plength, step, U[(size_t)b], P[(size_t)b]);
+        P[(size_t)b].status = status[b];
+    }
+    hipStream_t st = c->stream;
+    // ---- device: solver
+    const size_t bytes_prep = (size_t)B * sizeof(Prep), nsolbuf = (size_t)B * MAXSOL;
+    HIPCHK(c, c->d_rgb.reserve(bytes_prep + nsolbuf * 3 * sizeof(double) + (size_t)B * (2 * sizeof(int) + sizeof(unsigned long long)) + 64));
+    unsigned char *base = c->d_rgb.p;
+    Prep *d_prep = (Prep *)base;
+    double *d_sols = (double *)(base + ((bytes_prep + 15) & ~(size_t)15));
+    double *d_fl1 = d_sols + nsolbuf, *d_ksi = d_fl1 + nsolbuf;
+    unsigned long long *d_norm = (unsigned long long *)(d_ksi + nsolbuf);
+    int *d_nsol = (int *)(d_norm + B), *d_n1 = d_nsol + B;
+    HIPCHK(c, hipMemcpyAsync(d_prep, P.data(), bytes_prep, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(d_norm, 0, (size_t)B * (sizeof(unsigned long long) + 2 * sizeof(int)), st));
+    hipLaunchKernelGGL(k_armm_scan, dim3(MAXP, B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
+    hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
+    HIPCHK(c, hipGetLastError());
+    std::vector<int> n1((size_t)B);
+    std::vector<double> fl1(nsolbuf), ksi(nsolbuf);
+    HIPCHK(c, hipMemcpyAsync(n1.data(), d_nsol, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(fl1.data(), d_sols, nsolbuf * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // ---- host: frequency bias (models.cpp:4833-4842, :4873-4880)
+    for (int b = 0; b < B; b++) {
+        if (status[b] != TAMCMC_OK) { n1[(size_t)b] = 0; continue; }
+        if (n1[(size_t)b] > MAXSOL) { status[b] = TAMCMC_ERR_BAD_ARG; P[(size_t)b].status = status[b]; n1[(size_t)b] = 0; continue; }
+        const Unpacked &u = U[(size_t)b];
+        if (u.bias_type != 0) {
+            const double *p = params + (size_t)b * Nparams;
+            Spline s;
+            if (!s.set(p + u.o1 + 8, p + u.o1 + 8 + u.Nferr, u.Nferr, u.bias_type == 1 ? 1 : 2)) { status[b] = TAMCMC_ERR_BAD_ARG; n1[(size_t)b] = 0; continue; }
+            for (int i = 0; i < n1[(size_t)b]; i++) fl1[(size_t)b * MAXSOL + i] += s(fl1[(size_t)b * MAXSOL + i]);
+        }
+    }
+    // ---- device: zeta
+    HIPCHK(c, hipMemcpyAsync(d_fl1, fl1.data(), nsolbuf * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_n1, n1.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+    const int chunks = 64;
+    hipLaunchKernelGGL(k_zeta, dim3(chunks, B), dim3(WG), 0, st, d_prep, d_fl1, d_n1, d_ksi, d_norm, chunks);
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned long long> nb((size_t)B);
+    HIPCHK(c, hipMemcpyAsync(ksi.data(), d_ksi, nsolbuf * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(nb.data(), d_norm, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // ---- host: rows
+    int per = 1;
+    for (int b = 0; b < B; b++)
+        if (status[b] == TAMCMC_OK) per = std::max(per, U[(size_t)b].Nfl0 + n1[(size_t)b] + U[(size_t)b].Nfl2 + U[(size_t)b].Nfl3);
+    const StageLayout L(B, stride, (size_t)B * per);
+    HIPCHK(c, c->h_stage.reserve(L.bytes));
+    unsigned char *h = c->h_stage.p;
+    int32_t *pairs = (int32_t *)(h + L.off_pairs), *h_nh = (int32_t *)(h + L.off_nh), *h_nn = (int32_t *)(h + L.off_nn);
+    double *h_noise = (double *)(h + L.off_noise);
+    tamcmc_multiplet *h_mults = (tamcmc_multiplet *)(h + L.off_mults);
+    const mt::PolyTab &T = poly_table();
+    for (int b = 0; b < B; b++) {
+        int n = 0, stb = status[b];
+        tamcmc_multiplet *rows = h_mults + (size_t)b * per;
+        if (stb == TAMCMC_OK) {
+            const Unpacked &u = U[(size_t)b];
+            const double *p = params + (size_t)b * Nparams;
+            const double *fl0 = p + u.Nmax + u.lmax;
+            double norm;
+            std::memcpy(&norm, &nb[(size_t)b], sizeof norm);
+            double V[4][7] = {{1, 0, 0, 0, 0, 0, 0}};
+            for (int l = 1; l <= u.lmax; l++) mt::amplitude_ratio(l, u.inclination, V[l]);
+            auto add = [&](int l, double f, double H, double W, const double a[7], double eta0) {
+                tamcmc_multiplet *r = &rows[n];
+                int i0 = 0, i1 = 0;
+                const int rs = mt::set_imin_imax(hx[0], hx[Nx - 1], Nx, l, f, W, a[1], u.trunc_c, step, &i0, &i1);
+                if (rs) { stb = rs; return; }
+                r->l = l; r->i0 = i0; r->i1 = i1; r->flags = 0; r->fc = f; r->gamma = W; r->asym = u.asym;
+                for (int k = 0; k < 7; k++) { r->nu[k] = 0; r->hv[k] = 0; }
+                for (int m = -l; m <= l; m++) {
+                    r->nu[m + l] = l == 0 ? f : mt::nu_nlm_aj(T, f, a, eta0, l, m);
+                    r->hv[m + l] = H * V[l][m + l];
+                }
+                n++;
+            };
+            const double a0[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < u.Nfl0 && stb == TAMCMC_OK; k++) add(0, fl0[k], u.Hl0[(size_t)k], u.Wl0[(size_t)k], a0, 0.0);
+            // mixed modes: zeta -> height ratio, width, splitting (bump_DP.cpp:203-254, :531-547; models.cpp:4882-4906)
+            const int ni = u.Nfl0 + 4;
+            std::vector<double> fi((size_t)ni), hi((size_t)ni);
+            fi[0] = u.fmin * 0.6; fi[1] = u.fmin * 0.8; fi[(size_t)ni - 2] = u.fmax * 1.2; fi[(size_t)ni - 1] = u.fmax * 1.4;
+            hi[0] = 0; hi[1] = u.Hl0[0] / 4; hi[(size_t)ni - 2] = u.Hl0[(size_t)u.Nmax - 1] / 4; hi[(size_t)ni - 1] = 0;
+            for (int j = 0; j < u.Nfl0; j++) { fi[(size_t)j + 2] = fl0[j]; hi[(size_t)j + 2] = u.Hl0[(size_t)j]; }
+            for (int i = 0; i < n1[(size_t)b] && stb == TAMCMC_OK; i++) {
+                const double f = fl1[(size_t)b * MAXSOL + i];
+                double z = ksi[(size_t)b * MAXSOL + i] / norm;
+                if (z > 1) z = 1;
+                double hr = std::sqrt(1. - u.Hfactor * z);
+                if (hr > -1e-5 && hr < 1e-5) hr = 1e-10;
+                const double t = mt::lin_interpol(fi.data(), hi.data(), ni, f);
+                const double Hp = t < 0 ? 0.0 : std::fabs(t);
+                const double H = std::fabs(hr * (Hp * u.Vl[1]));
+                const double W = mt::lin_interpol(fl0, u.Wl0.data(), u.Nfl0, f) * (1. - u.Wfactor * z) / std::sqrt(hr);
+                const double a1[7] = {0, std::fabs(z * (u.rot_core / 2 - u.rot_env) + u.rot_env), 0, 0, 0, 0, 0};
+                add(1, f, H, W, a1, u.eta0);
+            }
+            const double a2[7] = {0, u.rot_env, p[u.os + 2], p[u.os + 4], p[u.os + 5], 0, 0};
+            for (int k = 0; k < u.Nfl2 && stb == TAMCMC_OK; k++) {
+                const double f = std::fabs(p[u.o1 + u.Nfl1 + k]), W = app_width(u.g, f);
+                double H = mt::lin_interpol(fl0, u.Hl0.data(), u.Nfl0, f);
+                H = u.do_amp ? (double)fabsl(H / ((long double)M_PI * W) * u.Vl[2]) : std::fabs(H * u.Vl[2]);
+                add(2, f, H, W, a2, u.eta0);
+            }
+            const double a3[7] = {0, u.rot_env, p[u.os + 2], p[u.os + 4], p[u.os + 5], p[u.os + 6], p[u.os + 7]};
+            for (int k = 0; k < u.Nfl3 && stb == TAMCMC_OK; k++) {
+                const double f = std::fabs(p[u.o1 + u.Nfl1 + u.Nfl2 + k]), W = app_width(u.g, f);
+                double H = mt::lin_interpol(fl0, u.Hl0.data(), u.Nfl0, f);
+                H = u.do_amp ? (double)fabsl(H / ((long double)M_PI * W) * u.Vl[3]) : std::fabs(H * u.Vl[3]);
+                add(3, f, H, W, a3, u.eta0);
+            }
+        }
+        status[b] = stb;
+        int nh = 0, nn = 1;
+        if (stb == TAMCMC_OK) {
+            const Unpacked &u = U[(size_t)b];
+            for (int k = 0; k < u.Nnoise; k++) h_noise[(size_t)b * stride + k] = std::fabs(params[(size_t)b * Nparams + u.onoise + k]);
+            nh = (u.Nnoise - 1) / 3; nn = u.Nnoise;
+        } else {
+            n = 0;
+            h_noise[(size_t)b * stride] = 1.0;  // placeholder row; logL[b] is overwritten with NaN
+        }
+        pairs[2 * b] = (int32_t)((size_t)b * per);
+        pairs[2 * b + 1] = (int32_t)((size_t)b * per + n);
+        h_nh[b] = nh; h_nn[b] = nn;
+    }
+    *first_err = TAMCMC_OK;
+    for (int b = 0; b < B; b++)
+        if (status[b] != TAMCMC_OK && *first_err == TAMCMC_OK) *first_err = status[b];
+    *per_out = per;
+    *stride_out = stride;
+    return TAMCMC_OK;
+}
+
+}  // namespace tamcmc

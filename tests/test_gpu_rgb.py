@@ -1,0 +1,57 @@
+"""Red-giant model (id 25, BASELINE config C5 family) on the device: the ARMM mixed-mode solver and the zeta function run as HIP
+kernels (csrc/rgb_prestep.hip), the variable-length table goes through the same k_loglike as the main-sequence models.
+Checked against the oracle's restatement (oracle/armm_oracle.c; parity unpinned by the reference, see that file)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bias_type,model_type", [(0, 0), (1, 0), (2, 1), (0, 1)])
+def test_rgb_model_rows_and_logl_match_the_oracle(pkg, oracle, synth, bias_type, model_type):
+    rng = np.random.default_rng(5)
+    params, pl = synth.make_params_rgb_model(rng, bias_type=bias_type, model_type=model_type)
+    step = 0.05
+    x = 110.0 + step * np.arange(3400)
+    st, m0 = oracle.call_model(synth.MODEL_RGB_V4, params, pl, x)
+    assert st == 0
+    y = m0 * np.random.default_rng(2).exponential(1.0, m0.size)
+    B = 5
+    P = np.tile(params, (B, 1))
+    o = np.cumsum([0] + list(pl))
+    P[1:, :pl[0]] *= 1 + 0.05 * rng.standard_normal((B - 1, pl[0]))                 # heights
+    P[1:, o[3] + 1] *= 1 + 0.002 * rng.standard_normal(B - 1)                        # period spacing: moves every mixed mode
+    P[1:, o[3] + 3] *= 1 + 0.05 * rng.standard_normal(B - 1)                         # coupling
+    T = 1.4 ** np.arange(B)
+    ref, m_o, st_o = oracle.loglike_batch(synth.MODEL_RGB_V4, P, pl, x, y, 1.0, T, want_model=True)
+    assert (st_o == 0).all()
+    for prec, tol_m, tol_l in ((pkg.PRECISION_STRICT, 1e-7, 1e-8), (pkg.PRECISION_FAST, 1e-7, 1e-8)):
+        ctx = pkg.HipContext(0, precision=prec)
+        ctx.set_spectrum(x, y)
+        got, m_d, st_d = ctx.loglike_params_batch(pkg.MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4, P, pl, T, want_model=True)
+        assert (st_d == 0).all()
+        # same mixed modes (a missing or extra mode would change the row by O(1) around it); frequencies agree to ~1e-10 muHz
+        # (device tan/atan in double vs the reference's long double), i.e. ~1e-8 relative on a 0.05 muHz-wide profile
+        rel = np.linalg.norm(m_d - m_o, axis=1) / np.linalg.norm(m_o, axis=1)
+        assert rel.max() < tol_m, rel
+        assert np.allclose(got, ref, rtol=tol_l, atol=0), np.abs(got / ref - 1).max()
+        ctx.close()
+
+
+def test_rgb_bad_vectors_are_reported_not_guessed(pkg, oracle, synth):
+    rng = np.random.default_rng(6)
+    params, pl = synth.make_params_rgb_model(rng)
+    x = 110.0 + 0.05 * np.arange(3400)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(x, np.ones_like(x))
+    P = np.tile(params, (3, 1))
+    o = np.cumsum([0] + list(pl))
+    P[1, o[3] + 1] = 1e9                       # period spacing so large that no g mode falls in the range: "impossible star"
+    P[2, o[2]:o[3]] = P[2, o[2]:o[3]][::-1]    # radial modes in decreasing order: negative large separation
+    got, _, st = ctx.loglike_params_batch(pkg.MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4, P, pl, None)
+    assert st[0] == 0 and np.isfinite(got[0])
+    assert st[2] != 0 and np.isnan(got[2])
+    # no g mode in range: the reference's solver returns an empty set and the model carries on without l=1 modes
+    ref, _, st_o = oracle.loglike_batch(synth.MODEL_RGB_V4, P[1:2], pl, x, np.ones_like(x), 1.0, None)
+    assert st[1] == 0 and st_o[0] == 0 and np.isclose(got[1], ref[0], rtol=1e-10)
+    ctx.close()

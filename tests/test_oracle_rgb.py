@@ -67,8 +67,8 @@ def test_solver_from_l0_uses_the_shifted_radial_modes(oracle):
     assert np.all(np.isin(np.round(l0 + 0.5 * s["dnup"][3] * 0 + 0.5 * np.polyfit(np.arange(6), l0, 1)[0] - 0.5, 6),
                           np.round(s["nu_p"], 6)))                                   # nu_p = nu_l0 + Dnu/2 + delta0l (:261-301)
     assert np.all((s["nu_m"] >= l0.min()) & (s["nu_m"] <= l0.max())) and s["nu_m"].size > 10
-    rc2, _ = oracle.armm_solve_O2p(Dnu, 0.2, 1, 0.0, 0.0, 0.0, 1e9, 0.0, q, 120.0, 260.0, resol)
-    assert rc2 != 0                                                                    # "impossible star": no g mode in range
+    rc2, s2 = oracle.armm_solve_O2p(Dnu, 0.2, 1, 0.0, 0.0, 0.0, 1e9, 0.0, q, 120.0, 260.0, resol)
+    assert rc2 == 0 and s2["nu_m"].size == 0                                          # "impossible star" (no g mode in range): empty set
 
 
 def test_zeta_is_a_normalised_inertia_ratio(oracle):
