@@ -40,6 +40,9 @@ extern "C" {
 #define TAMCMC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC 3 /* model_MS_Global_a1etaa3_HarveyLike_Classic, models.cpp:1943 */
 #define TAMCMC_MODEL_MS_LOCAL_BASIC 11           /* model_MS_local_basic, models.cpp:3012 */
 #define TAMCMC_MODEL_MS_GLOBAL_AJ 23             /* model_MS_Global_aj_HarveyLike, models.cpp:1195 */
+#define TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 25 /* model_RGB_asympt_aj_AppWidth_HarveyLike_v4, models.cpp:4684: only through
+                                                    tamcmc_hip_loglike_params_batch (its table needs the device pre-step:
+                                                    ARMM mixed-mode solver + zeta function, csrc/rgb_prestep.hip) */
 
 /* ---------------- arithmetic modes ---------------- */
 /* STRICT: per-bin operation order of the reference (IEEE divides, no FMA contraction): the model row is

@@ -816,9 +816,47 @@ long double orc_priors_local(const double *params, const int *pl, const double *
     return f;
 }
 
-/* call_prior (model_def.cpp:421-464): class 2 = io_MS_Global, 3 = io_local */
+/* priors_calc.cpp:319-512 -- model class io_asymptotic (red giants), model_switch 3 = the v4 models; the v3 branch
+ * (model_switch 1, l=1 p modes listed in the parameter vector) is not restated: NAN. */
+long double orc_priors_asymptotic(const double *params, const int *pl, const double *pr, const int *sw, const double *extra) {
+    long double f = 0;
+    const double scoef = extra[1], a3ova1_limit = extra[2];
+    const int model_switch = (int)extra[4];
+    const int Nmax = pl[0], lmax = pl[1], Nfl0 = pl[2], Nfl1 = pl[3], Nfl2 = pl[4], Nfl3 = pl[5], Nsplit = pl[6], Nwidth = pl[7];
+    const int Nf = Nfl0 + Nfl1 + Nfl2 + Nfl3;
+    long Np = 0;
+    for (int k = 0; k < 11; k++) Np += pl[k];
+    int i;
+    const int i0 = Nmax + lmax + Nf + Nsplit;
+    const double a3 = params[Nmax + lmax + Nf + 4], rot_env = fabs(params[Nmax + lmax + Nf]);
+    for (i = Nmax; i <= Nmax + lmax; i++)
+        if (params[i] < 0) return -INFINITY;
+    if (fabs(a3 / rot_env) >= a3ova1_limit) return -INFINITY;
+    const int on = Nmax + lmax + Nf + Nsplit + Nwidth;
+    if (sw[on + 3] != 0 && ((params[on + 3] < 0) || (params[on + 4] < 0) || (params[on + 5] < 0))) return -INFINITY;
+    if (sw[on + 6] != 0 && ((params[on + 6] < 0) || (params[on + 7] < 0) || (params[on + 8] < 0))) return -INFINITY;
+    if ((sw[Nmax + lmax + Nf + 9] != 0) && (params[on + 9] < 0)) return -INFINITY;
+    for (i = i0; i < i0 + Nwidth; i++)
+        if (sw[i] == 2 && params[i] < 0) return -INFINITY;
+    f = f + orc_apply_generic_priors(params, 0, Np, pr, Np, sw);
+    if (model_switch == 1) return NAN;
+    if (model_switch == 3) {
+        if (params[Nmax + lmax + Nfl0 + 6] < 0) return -INFINITY;
+        if (params[Nmax + lmax + Nfl0 + 7] < 0) return -INFINITY;
+    }
+    /* :466 -- the switch reads priors_names_switch[i] with i left at i0+Nwidth by the loop above */
+    if (sw[i] == 1) {
+        for (int k = 0; k < Nfl0; k++) f = f + orc_logP_gaussian(0, scoef, orc_second_difference(params + Nmax + lmax, Nfl0, k));
+        for (int k = 0; k < Nfl3; k++)
+            f = f + orc_logP_gaussian(0, scoef, orc_second_difference(params + Nmax + lmax + Nfl0 + Nfl1 + Nfl2, Nfl3, k));
+    }
+    return f;
+}
+
+/* call_prior (model_def.cpp:421-464): class 2 = io_MS_Global, 3 = io_local, 4 = io_asymptotic */
 double orc_call_prior(int prior_class, const double *params, const int *pl, const double *pr, const int *sw, const double *extra) {
     if (prior_class == 2) return (double)orc_priors_MS_Global(params, pl, pr, sw, extra);
     if (prior_class == 3) return (double)orc_priors_local(params, pl, pr, sw, extra);
+    if (prior_class == 4) return (double)orc_priors_asymptotic(params, pl, pr, sw, extra);
     return NAN;
 }

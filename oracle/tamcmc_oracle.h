@@ -152,6 +152,8 @@ long double orc_priors_MS_Global(const double *params, const int *plength, const
                                  const double *extra_priors);
 long double orc_priors_local(const double *params, const int *plength, const double *priors, const int *priors_names_switch,
                              const double *extra_priors);
+long double orc_priors_asymptotic(const double *params, const int *plength, const double *priors, const int *priors_names_switch,
+                                  const double *extra_priors);   /* priors_calc.cpp:319-512 */
 double orc_call_prior(int prior_class, const double *params, const int *plength, const double *priors,
                       const int *priors_names_switch, const double *extra_priors);
 

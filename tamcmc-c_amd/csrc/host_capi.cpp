@@ -269,6 +269,7 @@ double tamcmc_log_prior(int prior_class, const double *params, int64_t Nparams, 
     long double r;
     if (prior_class == 2) r = priors_MS_Global(params, pl, pp, sw, extra, &st);
     else if (prior_class == 3) r = priors_local(params, pl, pp, sw, extra, &st);
+    else if (prior_class == 4) r = priors_asymptotic(params, pl, pp, sw, extra, &st);
     else { st = TAMCMC_ERR_BAD_MODEL; r = NAN; }
     if (status) *status = st;
     return (double)r;

@@ -65,6 +65,7 @@ long double Model_def::call_prior_params(const double *p) {
     switch (prior_fct_name_switch) {  // Config/default/priors_ctrl.list
     case 2: r = priors_MS_Global(p, plength, priors_params, priors_params_names_switch, extra_priors, &st); break;
     case 3: r = priors_local(p, plength, priors_params, priors_params_names_switch, extra_priors, &st); break;
+    case 4: r = priors_asymptotic(p, plength, priors_params, priors_params_names_switch, extra_priors, &st); break;
     default: st = TAMCMC_ERR_BAD_MODEL; r = -std::numeric_limits<long double>::infinity(); break;
     }
     if (st != TAMCMC_OK) last_status = st;

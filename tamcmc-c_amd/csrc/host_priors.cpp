@@ -38,4 +38,9 @@ long double priors_local(const double *params, const std::vector<int> &pl, const
     return pr::prior_serial(3, params, pl.data(), nparams_of(pl), pp.a.data(), sw.data(), extra.data(), status);
 }
 
+long double priors_asymptotic(const double *params, const std::vector<int> &pl, const Matrix &pp, const std::vector<int> &sw,
+                              const std::vector<double> &extra, int *status) {
+    return pr::prior_serial(4, params, pl.data(), nparams_of(pl), pp.a.data(), sw.data(), extra.data(), status);
+}
+
 }  // namespace tamcmc

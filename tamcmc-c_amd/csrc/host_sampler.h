@@ -85,6 +85,8 @@ long double priors_MS_Global(const double *params, const std::vector<int> &pleng
                              const std::vector<int> &priors_names_switch, const std::vector<double> &extra_priors, int *status);
 long double priors_local(const double *params, const std::vector<int> &plength, const Matrix &priors_params,
                          const std::vector<int> &priors_names_switch, const std::vector<double> &extra_priors, int *status);
+long double priors_asymptotic(const double *params, const std::vector<int> &plength, const Matrix &priors_params,
+                         const std::vector<int> &priors_names_switch, const std::vector<double> &extra_priors, int *status);  // priors_calc.cpp:319-512
 
 class Model_def {  // model_def.h:27-85
     std::vector<double> cons;

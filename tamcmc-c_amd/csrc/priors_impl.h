@@ -234,6 +234,39 @@ TM_HD xreal prior_serial(int prior_class, const double *params, const int *pl, l
         for (long i = 0; i < Np; i++) f = f + generic_prior_term(params, Np, pp, sw, i, status);
         return f;
     }
+    if (prior_class == 4) {  // io_asymptotic: priors_asymptotic, priors_calc.cpp:319-512 (host engine only: the RGB model's pre-step)
+        const int Nmax = pl[0], lmax = pl[1], Nfl0 = pl[2], Nfl1 = pl[3], Nfl2 = pl[4], Nfl3 = pl[5], Nsplit = pl[6], Nwidth = pl[7];
+        const int Nf = Nfl0 + Nfl1 + Nfl2 + Nfl3;
+        const double scoef = extra[1], a3ova1_limit = extra[2];
+        const int model_switch = (int)extra[4];
+        const int i0 = Nmax + lmax + Nf + Nsplit, on = i0 + Nwidth;
+        const double a3 = params[Nmax + lmax + Nf + 4], rot_env = fabs(params[Nmax + lmax + Nf]);
+        for (int i = Nmax; i <= Nmax + lmax; i++)  // (one past the visibilities, as the reference's loop bound)
+            if (params[i] < 0) return neg_inf();
+        if (fabs(a3 / rot_env) >= a3ova1_limit) return neg_inf();
+        if (sw[on + 3] != 0 && ((params[on + 3] < 0) || (params[on + 4] < 0) || (params[on + 5] < 0))) return neg_inf();
+        if (sw[on + 6] != 0 && ((params[on + 6] < 0) || (params[on + 7] < 0) || (params[on + 8] < 0))) return neg_inf();
+        if ((sw[Nmax + lmax + Nf + 9] != 0) && (params[on + 9] < 0)) return neg_inf();  // index as in priors_calc.cpp:391
+        for (int i = i0; i < i0 + Nwidth; i++)
+            if (sw[i] == 2 && params[i] < 0) return neg_inf();  // Gaussian priors on the width law: positive support only
+        for (long i = 0; i < Np; i++) f = f + generic_prior_term(params, Np, pp, sw, i, status);
+        if (model_switch == 1) {  // the v3 models (l=1 p-mode list in the parameter vector): not built here
+            if (status) *status = TAMCMC_ERR_BAD_MODEL;
+            return neg_inf();
+        }
+        if (model_switch == 3) {
+            if (params[Nmax + lmax + Nfl0 + 6] < 0) return neg_inf();  // Wfactor
+            if (params[Nmax + lmax + Nfl0 + 7] < 0) return neg_inf();  // Hfactor
+        }
+        // smoothness of the l=0 and l=3 ladders.  The reference switches it on the prior id of parameter i0+Nwidth -- the loop
+        // variable left over from the width check above (priors_calc.cpp:466; most likely meant extra_priors[0]) -- kept as is.
+        if (sw[on] == 1) {
+            for (int i = 0; i < Nfl0; i++) f = f + logP_gaussian(0, scoef, second_difference(params + Nmax + lmax, Nfl0, i));
+            for (int i = 0; i < Nfl3; i++)
+                f = f + logP_gaussian(0, scoef, second_difference(params + Nmax + lmax + Nfl0 + Nfl1 + Nfl2, Nfl3, i));
+        }
+        return f;
+    }
     if (status) *status = TAMCMC_ERR_BAD_MODEL;
     return neg_inf();
 }

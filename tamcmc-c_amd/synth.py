@@ -209,7 +209,7 @@ def make_params_rgb_model(rng, nmax=6, dnu=20.0, epsilon=0.2, n_first=6, delta0l
     vis = np.array([1.5, 0.53, 0.08])
     fref = (n_first + 1 + np.arange(nferr) * max((nmax - 2) / max(nferr - 1, 1), 1) + epsilon + 0.5) * dnu
     ferr = rng.uniform(-ferr_scale, ferr_scale, nferr) if bias_type != 0 else np.zeros(nferr)
-    l1 = np.concatenate([[delta0l, DPl, alpha_g, q, 0.0, 0.0, 1.0, 1.0], fref, ferr])
+    l1 = np.concatenate([[delta0l, DPl, alpha_g, q, 0.0, 0.0, 0.9, 0.9], fref, ferr])   # Wfactor, Hfactor < 1: zeta = 1 keeps a finite mode
     fl2 = fl0[1:] - 0.12 * dnu
     fl3 = fl0[:-1] + 0.21 * dnu
     split = np.array([rot_env, rot_core, 0.0, 0.0, 0.01, 0.0, 0.0, 0.0, 1.0, 0.0])
@@ -220,3 +220,52 @@ def make_params_rgb_model(rng, nmax=6, dnu=20.0, epsilon=0.2, n_first=6, delta0l
     plength = np.array([nmax, 3, nmax, l1.size, fl2.size, fl3.size, 10, 6, 7, 1, 6], dtype=np.int32)
     assert params.size == plength.sum()
     return params, plength
+
+
+def make_c5_star(seed=20240229, nx=200000, nmax=10, dnu=10.0, bias_type=1, model_type=0, nferr=6, margin=15.0):
+    """BASELINE config C5 family: red giant, model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (id 25), prior class io_asymptotic (4).
+    The l=1 mixed modes are not parameters: they follow from (delta0l, DPl, alpha_g, q) through the ARMM solver."""
+    rng = np.random.default_rng(seed)
+    params, plength = make_params_rgb_model(rng, nmax=nmax, dnu=dnu, n_first=6, DPl=80.0, q=0.15, nferr=nferr, bias_type=bias_type,
+                                            model_type=model_type)
+    o = np.cumsum([0] + list(plength))
+    names = (["Height_l0"] * nmax + ["Visibility_l1", "Visibility_l2", "Visibility_l3"] + ["Frequency_l"] * nmax +
+             ["delta01", "DP1", "alpha_g", "q", "sigma_H_l1", "sigma_g_l1", "Wfactor", "Hfactor"] + ["fref_bias"] * nferr + ["ferr_bias"] * nferr +
+             ["Frequency_l"] * (plength[4] + plength[5]) +
+             ["rot_env", "rot_core", "a2_env", "a2_core", "a3_env", "a4_env", "a5_env", "a6_env", "eta0_switch", "Lorentzian_asymetry"] +
+             ["numax", "nudip", "alpha", "Gamma_alpha", "Wdip", "DeltaGammadip"] +
+             ["Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p", "Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p", "White_Noise_N0"] +
+             ["Inclination", "Truncation_parameter", "do_amp", "sigma_limit", "model_type", "bias_type", "Nferr"])
+    assert len(names) == params.size
+    relax = np.zeros(params.size, dtype=np.int32)
+    relax[:nmax] = 1                                        # heights
+    relax[o[2]:o[3]] = 1                                    # l=0 frequencies
+    relax[[o[3], o[3] + 1, o[3] + 3, o[3] + 6, o[3] + 7]] = 1   # delta01, DP1, q, Wfactor, Hfactor
+    if bias_type != 0:
+        relax[o[3] + 8 + nferr:o[4]] = 1                    # bias values at the spline nodes
+    relax[o[4]:o[6]] = 1                                    # l=2, l=3 frequencies
+    relax[[o[6], o[6] + 1]] = 1                             # envelope and core rotation
+    relax[o[7]:o[8]] = 1                                    # width law
+    relax[[o[8], o[8] + 3, o[8] + 6]] = 1                   # Harvey heights, white noise
+    relax[o[9]] = 1                                         # inclination
+    rules = {
+        "Height_l0": (P_JEFF, lambda v: (0.1, 1.0e4)),
+        "Frequency_l": (P_UNIFORM, lambda v: (v - 0.3 * dnu / 10.0 * 3, v + 0.3 * dnu / 10.0 * 3)),
+        "delta01": (P_UNIFORM, lambda v: (v - 1.0, v + 1.0)),
+        "DP1": (P_UNIFORM, lambda v: (v - 1.0, v + 1.0)),
+        "q": (P_UNIFORM, lambda v: (0.0, 1.0)),
+        "Wfactor": (P_UNIFORM, lambda v: (0.0, 1.0)), "Hfactor": (P_UNIFORM, lambda v: (0.0, 1.0)),
+        "ferr_bias": (P_GAUSS, lambda v: (0.0, 0.1)),
+        "rot_env": (P_UNIFORM, lambda v: (0.0, 1.0)), "rot_core": (P_UNIFORM, lambda v: (0.0, 3.0)),
+        "numax": (P_GAUSS, lambda v: (v, 0.05 * v)), "nudip": (P_GAUSS, lambda v: (v, 0.05 * v)), "alpha": (P_GAUSS, lambda v: (v, 0.3)),
+        "Gamma_alpha": (P_GAUSS, lambda v: (v, 0.05)), "Wdip": (P_GAUSS, lambda v: (v, 0.1 * v)), "DeltaGammadip": (P_GAUSS, lambda v: (v, 0.3)),
+        "Harvey-Noise_H": (P_UNIFORM, lambda v: (0.0, 500.0)), "White_Noise_N0": (P_UNIFORM, lambda v: (0.0, 50.0)),
+        "Inclination": (P_UNIFORM, lambda v: (0.0, 90.0)),
+    }
+    pr, sw = _prior_tables(names, params, relax, rules)
+    fl0 = params[o[2]:o[3]]
+    lo, hi = fl0.min() - margin, fl0.max() + margin
+    x = lo + (hi - lo) / nx * np.arange(nx)
+    # extra_priors (io_asymptotic.cpp:422-431): [smooth switch, smooth coef, |a3/a1| limit, impose_normHnlm, model switch 3 = v4 models]
+    extra = np.array([1.0, 2.0, 0.2, 0.0, 3.0, 0, 0, 0, 0, 0])
+    return Star(MODEL_RGB_V4, params, plength, x, relax, pr, sw, names, prior_class=4, extra_priors=extra)

@@ -55,3 +55,28 @@ def test_rgb_bad_vectors_are_reported_not_guessed(pkg, oracle, synth):
     ref, _, st_o = oracle.loglike_batch(synth.MODEL_RGB_V4, P[1:2], pl, x, np.ones_like(x), 1.0, None)
     assert st[1] == 0 and st_o[0] == 0 and np.isclose(got[1], ref[0], rtol=1e-10)
     ctx.close()
+
+
+def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth):
+    """Red-giant star end to end: priors (io_asymptotic) on the host, ONE batched device call per iteration whose tables come from
+    the device pre-step, adaptive MH + parallel tempering (host-driven engine; the device-resident engine does not carry the
+    pre-step yet and must refuse the model)."""
+    star = synth.make_c5_star(nx=6000, nmax=6, nferr=4)
+    st, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+    assert st == 0
+    star.set_spectrum_from_model(m0, 4)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, star.y)
+    s = pkg.Sampler(ctx, star, nchains=4, lambda_temp=1.6, seed=3, engine="host", Nt_learn=(20, 200), periods_learn=(1,))
+    st0 = s.state()
+    T = 1.6 ** np.arange(4)
+    ref, _, so = oracle.loglike_batch(star.model_id, np.tile(star.params, (4, 1)), star.plength, star.x, star.y, 1.0, T)
+    assert (so == 0).all() and np.allclose(st0["logL"], ref, rtol=1e-8) and np.isfinite(st0["logPrior"]).all()
+    smp, stat = s.run(150, stats=True)
+    assert np.isfinite(stat).all() and s.state()["iteration"] == 150
+    assert (smp[:, 0] != smp[0, 0]).any() and s.state()["swap_attempts"] == 149
+    assert stat[-50:, 0, 2].mean() > st0["logPost"][0] - 30.0
+    s.close()
+    with pytest.raises(pkg.TamcmcError):
+        pkg.Sampler(ctx, star, nchains=4, engine="device")
+    ctx.close()

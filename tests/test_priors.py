@@ -69,3 +69,37 @@ def _with_extra(star, i, v):
     s.extra_priors = star.extra_priors.copy()
     s.extra_priors[i] = v
     return s
+
+
+def test_asymptotic_priors_match_oracle(pkg, oracle, synth):
+    """Prior class io_asymptotic (priors_asymptotic, priors_calc.cpp:319-512) for the red-giant model: product host code vs oracle,
+    incl. the hard constraints and the smoothness terms (which the reference switches on the prior id of the first noise
+    parameter -- kept, see csrc/priors_impl.h)."""
+    from tamcmc_c_amd import sampler
+    star = synth.make_c5_star(nx=2000, nmax=7)
+    o = np.cumsum([0] + list(star.plength))
+    rng = np.random.default_rng(3)
+    base = star.params.copy()
+    cases = [base]
+    for _ in range(6):
+        p = base.copy()
+        p[star.index_to_relax] *= 1 + 1e-3 * rng.standard_normal(star.nvars)
+        cases.append(p)
+    bad = {"negative visibility": (o[1], -0.1), "a3/a1 over the limit": (o[6] + 4, 0.5), "negative Wfactor": (o[3] + 6, -0.2),
+           "negative Hfactor": (o[3] + 7, -0.2), "negative width-law parameter": (o[7] + 2, -1.0), "outside a uniform prior": (o[3] + 3, 1.5)}
+    for k, (idx, val) in bad.items():
+        p = base.copy()
+        p[idx] = val
+        cases.append(p)
+    got = np.array([sampler.log_prior(star, p)[0] for p in cases])
+    ref = np.array([oracle.call_prior(star, p) for p in cases])
+    assert np.all(np.isfinite(ref[:7])) and np.all(ref[7:] == -np.inf)
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref)) and np.allclose(got[:7], ref[:7], rtol=1e-14)
+    # smoothness: active because the first noise parameter carries a Uniform prior (id 1); a kink in the l=0 ladder is penalised
+    assert star.priors_switch[o[8]] == 1
+    p = base.copy()
+    p[o[2] + 3] += 0.4
+    d = sampler.log_prior(star, p)[0] - got[0]
+    sd = lambda y: np.array([y[2] - 2 * y[1] + y[0]] + list(y[2:] - 2 * y[1:-1] + y[:-2]) + [y[-1] - 2 * y[-2] + y[-3]])
+    want = -0.5 * (np.sum(sd(p[o[2]:o[3]]) ** 2) - np.sum(sd(base[o[2]:o[3]]) ** 2)) / 2.0 ** 2
+    assert np.isclose(d, want, rtol=1e-9)
