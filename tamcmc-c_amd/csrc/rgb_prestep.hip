@@ -7,7 +7,7 @@
 //            one workgroup per (parameter vector, p mode); sort + tolerance-unique per vector                     :586-593
 //   host   : + spline bias of the frequencies (cubic / Hermite, natural ends)            external/spline/src/spline.h:242-498
 //   device : zeta function at the mixed modes and its normalisation, max over a 4-year-resolution grid of the
-//            sum over all (p, g) pairs                                                  external/ARMM/bump_DP.cpp:46-78, :125-188
+//            sum over all (p, g) pairs (collapsed to one term per p mode, see ksi_sum)   external/ARMM/bump_DP.cpp:46-78, :125-188
 //   host   : mixed-mode heights / widths / rotational splittings, windows, table rows    bump_DP.cpp:203-254, :531-547; models.cpp:4867-5000
 //
 // The reference runs the solver for every (p mode, g mode) pair whose g mode lies within the search zone of the p mode.  g(nu)
@@ -180,13 +180,13 @@ __device__ __forceinline__ double ksi_one(double nu, double nu_p, double nu_g, d
     const double cu = cos(up), cd = cos(down);
     return 1. / (1. + front * ((cu * cu) / (cd * cd)));
 }
-__device__ __forceinline__ double ksi_sum(const Prep &P, double nu) {  // sum over all (p, g) pairs, the reference's order
+// Sum over all (p, g) pairs.  cos^2 has period pi and the g ladder is regular (1e6/(nu_g DPl) = n_g + alpha), so the term does not
+// depend on WHICH g mode is used: the reference's inner loop over the g modes adds L_g copies of the same number (up to the
+// rounding of its argument, ~1e-13 relative); here it is evaluated once, with the ladder's middle mode, and multiplied.
+__device__ __forceinline__ double ksi_sum(const Prep &P, double nu) {
+    const double nu_g = nu_g_of(P, P.Lg / 2);
     double s = 0;
-    for (int ip = 0; ip < P.Lp; ip++) {
-        double loc = 0;
-        for (int ig = 0; ig < P.Lg; ig++) loc += ksi_one(nu, P.nu_p[ip], nu_g_of(P, ig), P.dnup[ip], P.DPl, P.q);
-        s += loc;
-    }
+    for (int ip = 0; ip < P.Lp; ip++) s += (double)P.Lg * ksi_one(nu, P.nu_p[ip], nu_g, P.dnup[ip], P.DPl, P.q);
     return s;
 }
 

@@ -161,7 +161,11 @@ def default_errors(star):
     (error = fraction*value + offset per parameter family)."""
     rules = {"Height": (0.05, 0.0), "Visibility": (0.03, 0.0), "Frequency": (0.0, 0.05), "Width": (0.05, 0.0),
              "a1_0": (0.05, 0.01), "sqrt(splitting_a1)": (0.03, 0.01), "Harvey-Noise_H": (0.02, 0.0),
-             "Harvey-Noise_tc": (0.02, 0.0), "White_Noise_N0": (0.01, 0.0), "Inclination": (0.0, 1.0)}
+             "Harvey-Noise_tc": (0.02, 0.0), "White_Noise_N0": (0.01, 0.0), "Inclination": (0.0, 1.0),
+             # red-giant parameters: the mixed-mode pattern is very sensitive to the period spacing
+             "DP1": (0.0, 0.002), "delta01": (0.0, 0.01), "q": (0.02, 0.0), "Wfactor": (0.0, 0.02), "Hfactor": (0.0, 0.02),
+             "rot_": (0.05, 0.005), "ferr_bias": (0.0, 0.005), "numax": (0.005, 0.0), "nudip": (0.005, 0.0), "alpha": (0.01, 0.0),
+             "Gamma_alpha": (0.02, 0.0), "Wdip": (0.01, 0.0), "DeltaGammadip": (0.02, 0.0)}
     err = []
     for i in np.flatnonzero(star.relax == 1):
         nm = star.names[i]

@@ -42,3 +42,16 @@ if len(sys.argv) > 2:
     ref, _, so = orc.loglike_batch(synth.MODEL_RGB_V4, P[:4], pl, x, y, 1.0, T[:4])
     t1 = time.perf_counter() - t0
     print(f"oracle (CPU, OpenMP): {t1/4*1e3:.1f} ms per evaluation; max |dlogL/logL| {np.abs(logL[:4]/ref-1).max():.2e}")
+# host-driven sampler on the same star: 40 tempered chains (BASELINE config C5 asks for 40; the reference caps at 24)
+star = synth.make_c5_star(nx=Nx, nmax=nmax, dnu=10.0, bias_type=1, nferr=6)
+c.set_spectrum(star.x, np.ones(Nx))
+_, m, st = c.loglike_params_batch(star.model_id, star.params, star.plength, want_model=True)
+star.set_spectrum_from_model(m[0], 7)
+c.set_spectrum(star.x, star.y)
+s = pkg.Sampler(c, star, nchains=40, lambda_temp=1.15, seed=5, engine="host", Nt_learn=(10, 150), periods_learn=(1,))
+s.run(150, record=False)   # adaptation phase
+t0 = time.perf_counter(); n = 200
+s.run(n, record=False)
+dt = time.perf_counter() - t0
+stt = s.state()
+print(f"C5-like MH, 40 chains, host-driven engine: {n/dt:.1f} samples/s ({dt/n*1e3:.2f} ms per iteration), chain-0 acceptance over the run {stt['accepted0']/(150+n):.2f}", flush=True)
