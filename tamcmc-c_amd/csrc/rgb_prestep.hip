@@ -75,15 +75,16 @@ __global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sol
     __shared__ int s_nc;
     if (tid == 0) s_nc = 0;
     __syncthreads();
-    // ---- scan: candidate = index i with a sign change between grid points i and i+1
+    // ---- scan: candidate = index i with a sign change between grid points i and i+1.  Each lane evaluates ONE point; its right
+    //      neighbour's value comes from the next lane (the last lane of a wave evaluates that one point more)
     for (long i0 = 0; i0 < n - 1; i0 += WG) {
         const long i = i0 + tid;
-        if (i < n - 1) {
-            const double fa = f_pg(grid(i), nu_p, nu_g, Dl, P.DPl, P.q), fb = f_pg(grid(i + 1), nu_p, nu_g, Dl, P.DPl, P.q);
-            if (changes_sign(fa, fb)) {
-                const int k = atomicAdd(&s_nc, 1);
-                if (k < 512) s_cand[k] = i;
-            }
+        const double fa = (i < n) ? f_pg(grid(i), nu_p, nu_g, Dl, P.DPl, P.q) : 0.0;
+        double fb = __shfl_down(fa, 1, 64);
+        if (lane == 63 && i + 1 < n) fb = f_pg(grid(i + 1), nu_p, nu_g, Dl, P.DPl, P.q);
+        if (i < n - 1 && changes_sign(fa, fb)) {
+            const int k = atomicAdd(&s_nc, 1);
+            if (k < 512) s_cand[k] = i;
         }
     }
     __syncthreads();
@@ -102,17 +103,43 @@ __global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sol
         auto lg = [&](long j) { return (j == nl - 1) ? rmax : rmin + (double)j * ls; };
         auto fl = [&](long j) { return f_pg(lg(j), nu_p, nu_g, Dl, P.DPl, P.q); };
         const double f_first = fl(0), f_last = fl(nl - 1);
-        // first j with f[j] <= 0 <= f[j+1]
+        // first j with f[j] <= 0 <= f[j+1] -- only needed when lin_interpol interpolates (f_first <= 0 <= f_last); otherwise it
+        // extrapolates from the first or last two points (a pole of tan(): half of all candidates) and no search is made
         long best = nl;
-        for (long j0 = 0; j0 < nl - 1; j0 += 64) {
-            const long j = j0 + lane;
-            bool hit = false;
-            if (j < nl - 1) {
-                const double fa = fl(j), fb = fl(j + 1);
-                hit = !(0.0 < fa || 0.0 > fb);  // the loop condition of lin_interpol, negated
+        if (!(0.0 < f_first) && !(0.0 > f_last)) {
+            // poles of tan X sit where kappa(nu) = 1e6/DPl (1/nu - 1/nu_g) is a half-integer; without one inside the window p-g is
+            // continuous and increasing there, so the first bracketing segment is THE sign change: 64-ary search, two rounds
+            const double ka = 1e6 / P.DPl * (1. / rmin - 1. / nu_g) - 0.5, kb = 1e6 / P.DPl * (1. / rmax - 1. / nu_g) - 0.5;
+            const bool pole_inside = (floor(ka) != floor(kb)) || fabs(ka - rint(ka)) < 1e-9 || fabs(kb - rint(kb)) < 1e-9;
+            if (!pole_inside) {
+                long lo_j = 0, hi_j = nl - 1;  // invariant: f[lo_j] <= 0 <= f[hi_j]
+                while (hi_j - lo_j > 1) {
+                    const long span = hi_j - lo_j, stride = (span + 63) / 64;
+                    const long j = lo_j + (long)lane * stride;
+                    const bool neg = (j < hi_j) ? (fl(j) <= 0.0) : false;   // lanes beyond the interval count as "positive side"
+                    const unsigned long long m = __ballot(neg);
+                    const int last_neg = 63 - __clzll((long long)m);           // lane 0 is always on the negative side (f[lo_j] <= 0)
+                    const long nlo = lo_j + (long)last_neg * stride;
+                    long nhi = nlo + stride;
+                    if (nhi > hi_j) nhi = hi_j;
+                    lo_j = nlo; hi_j = nhi;
+                }
+                // the segment [lo_j, lo_j+1] has f[lo_j] <= 0 and f[lo_j+1] >= 0 up to the strictness of the two tests: step back
+                // over exact zeros so that the FIRST segment satisfying f[j] <= 0 <= f[j+1] is returned
+                best = lo_j;
+                while (best > 0 && fl(best - 1) <= 0.0 && fl(best) >= 0.0 && !(fl(best) > 0.0)) best--;
+            } else {
+                for (long j0 = 0; j0 < nl - 1; j0 += 64) {
+                    const long j = j0 + lane;
+                    bool hit = false;
+                    if (j < nl - 1) {
+                        const double fa = fl(j), fb = fl(j + 1);
+                        hit = !(0.0 < fa || 0.0 > fb);  // the loop condition of lin_interpol, negated
+                    }
+                    const unsigned long long m = __ballot(hit);
+                    if (m) { best = j0 + (long)(__ffsll((long long)m) - 1); break; }
+                }
             }
-            const unsigned long long m = __ballot(hit);
-            if (m) { best = j0 + (long)(__ffsll((long long)m) - 1); break; }
         }
         if (lane == 0) {
             double a = 0, bb = 0;
