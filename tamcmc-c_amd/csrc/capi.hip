@@ -214,6 +214,7 @@ static int stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *pa
     const double *hx = c->hx.data();
     const int64_t Nx = c->Nx;
     const int nthreads = B >= 8 ? (B < 16 ? B : 16) : 1;
+    (void)nthreads;  // (only the host pass sees the OpenMP pragma)
 #pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
     for (int b = 0; b < B; b++) {
         int n = 0, nh = 0, nn = 0;

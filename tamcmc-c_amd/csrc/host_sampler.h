@@ -134,7 +134,7 @@ class Model_def {  // model_def.h:27-85
 
 class MALA {  // MALA.h:26-69
     uint64_t seed;
-    long initial_i = 0, Nsamples, Nchains, Nvars;
+    long Nsamples, Nchains, Nvars;
     std::vector<long> Nt_learn, periods_learn;
     long dN_mixing;
     long double epsilon1, A1, delta, delta_x, c0, gamma, lambda_temp, target_acceptance;

@@ -173,3 +173,24 @@ def test_initial_errors_from_the_errors_file(inputs):
     want = [0.02 * v[0] + 0.01, 0.02 * v[1] + 0.01, 0.07, 0.07, 0.1 * v[4] + 0.05, 1.0, 0.015 * v[6] + 0.005, 0.015 * v[7] + 0.005,
             0.015 * v[8] + 0.0002]                                          # ".sini" has no row in this fixture -> 1
     assert np.allclose(e, want, rtol=1e-15)
+
+
+def test_parsers_survive_malformed_input_under_sanitizers(tmp_path):
+    """The front end's C++ (csrc/host_io.cpp, csrc/host_cfg.cpp) built for the CPU with AddressSanitizer + UBSan, fed every prefix,
+    line deletion and junk-line substitution of the fixtures: errors must be codes, never memory errors (the reference exits or
+    reads out of bounds on such input)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tamcmc-c_amd", "csrc")
+    exe = str(tmp_path / "fuzz")
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+           os.path.join(root, "tests", "parser_fuzz_driver.cpp"), os.path.join(src, "host_io.cpp"), os.path.join(src, "host_cfg.cpp")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    files = [MODEL, SUN, DATA, os.path.join(GOLD, "sampler_test.cfg"), os.path.join(GOLD, "errors_test.cfg")]
+    r = subprocess.run([exe, str(tmp_path / "variant.txt")] + files, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "variants" in r.stdout
