@@ -6,13 +6,13 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 lines = [f"# rocprofv3 summary {tag} (MI355X, one GPU)", ""]
 def newest(pattern):
-    """gpurun merges new files over old ones: keep the files of the highest run id only."""
+    """gpurun merges new files over old ones (run ids are process ids, not ordered): keep the files of the most recent run."""
     fs = glob.glob(pattern)
     if not fs:
         return []
-    rid = lambda f: int(os.path.basename(f).split("_")[0]) if os.path.basename(f).split("_")[0].isdigit() else -1
-    top = max(rid(f) for f in fs)
-    return [f for f in fs if rid(f) == top]
+    rid = lambda f: os.path.basename(f).split("_")[0]
+    last = max(fs, key=os.path.getmtime)
+    return [f for f in fs if rid(f) == rid(last)]
 
 
 ks = newest(f"{src}/trace/*/*kernel_stats.csv")
