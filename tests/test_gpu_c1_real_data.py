@@ -1,7 +1,8 @@
 """BASELINE config C1: the reference's own sample input test/inputs/TF_3443483_local-v3 (.data slice 1: 973 bins of a real
 Kepler red-giant spectrum, committed as tests/golden/TF_3443483_local-v3_slice1.data; model_MS_local_basic, the two modes
 of that slice as listed in the .model file: l=0 at 99.1056 muHz, l=2 at 97.7716 muHz), 4 tempered chains.
-The parameter vector is assembled by hand from the .model's eigen/noise tables (the .model parser is row N2, not built yet)."""
+The first test assembles the parameter vector by hand from the .model's eigen/noise tables; test_c1_from_the_shipped_files goes
+through the `.model`/`.data` loaders (include/tamcmc_io.h)."""
 import os
 
 import numpy as np
