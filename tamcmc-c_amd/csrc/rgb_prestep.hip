@@ -36,6 +36,7 @@ namespace rgb {
 constexpr int MAXP = 32;      // p modes per vector (fmax-fmin+2 Dnu)/Dnu + margins
 constexpr int MAXSOL = 1024;  // mixed modes per vector before de-duplication
 constexpr int WG = 256;
+constexpr int SEG = 12;        // workgroups per (vector, p mode): each scans one segment of the grid and refines its own candidates
 
 struct Prep {  // one parameter vector's solver inputs
     int Lp, Lg, ng_min, status;
@@ -57,9 +58,9 @@ __device__ __forceinline__ bool changes_sign(double a, double b) {  // sign_chan
     return ((b >= 0 && a < 0) || (b > 0 && a <= 0)) || (b <= 0 && a >= 0);
 }
 
-// One workgroup per (vector b, p mode ip).
+// SEG workgroups per (vector b, p mode ip).
 __global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sols, int *nsol) {
-    const int b = blockIdx.y, ip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, ip = blockIdx.x / SEG, seg = blockIdx.x % SEG, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Prep &P = preps[b];
     if (ip >= P.Lp || P.status != 0 || P.ig0[ip] < 0) return;
     const double nu_p = P.nu_p[ip], Dl = P.dnu_loc[ip], nu_g = nu_g_of(P, P.ig0[ip]);
@@ -77,12 +78,13 @@ __global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sol
     __syncthreads();
     // ---- scan: candidate = index i with a sign change between grid points i and i+1.  Each lane evaluates ONE point; its right
     //      neighbour's value comes from the next lane (the last lane of a wave evaluates that one point more)
-    for (long i0 = 0; i0 < n - 1; i0 += WG) {
+    const long seg_lo = (n - 1) * seg / SEG, seg_hi = (n - 1) * (seg + 1) / SEG;  // pairs (i, i+1) with seg_lo <= i < seg_hi
+    for (long i0 = seg_lo; i0 < seg_hi; i0 += WG) {
         const long i = i0 + tid;
         const double fa = (i < n) ? f_pg(grid(i), nu_p, nu_g, Dl, P.DPl, P.q) : 0.0;
         double fb = __shfl_down(fa, 1, 64);
         if (lane == 63 && i + 1 < n) fb = f_pg(grid(i + 1), nu_p, nu_g, Dl, P.DPl, P.q);
-        if (i < n - 1 && changes_sign(fa, fb)) {
+        if (i < seg_hi && changes_sign(fa, fb)) {
             const int k = atomicAdd(&s_nc, 1);
             if (k < 512) s_cand[k] = i;
         }
@@ -453,7 +455,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Npa
     int *d_nsol = (int *)(d_norm + B), *d_n1 = d_nsol + B;
     HIPCHK(c, hipMemcpyAsync(d_prep, P.data(), bytes_prep, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(d_norm, 0, (size_t)B * (sizeof(unsigned long long) + 2 * sizeof(int)), st));
-    hipLaunchKernelGGL(k_armm_scan, dim3(MAXP, B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
+    hipLaunchKernelGGL(k_armm_scan, dim3(MAXP * SEG, B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
     hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
     HIPCHK(c, hipGetLastError());
     std::vector<int> n1((size_t)B);
