@@ -103,8 +103,9 @@ int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *c, const double *x, const double *y,
 }
 
 // Launch on the tables staged in c->h_stage (layout L).
+// device_tables: the block is already in c->d_stage (built there by device kernels); tile_rot then comes from the caller.
 static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_stride, const double *Tcoefs, double p,
-                      double *logL, double *model) {
+                      double *logL, double *model, bool device_tables = false, int tile_rot = 0) {
     const int Nx = (int)c->Nx;
     const int tb = tamcmc::tile_bins(c->wgs, c->K);
     const int ntiles = (Nx + tb - 1) / tb;
@@ -114,7 +115,7 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     HIPCHK(c, c->h_S.reserve((size_t)B));
     if (model) HIPCHK(c, c->d_model.reserve((size_t)B * Nx));
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage.p, L.bytes, hipMemcpyHostToDevice, st));
+    if (!device_tables) HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage.p, L.bytes, hipMemcpyHostToDevice, st));
 
     tamcmc::LoglikeArgs a;
     a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.B = B; a.ntiles = ntiles;
@@ -127,7 +128,8 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     a.nnoise = (const int32_t *)(c->d_stage.p + L.off_nn);
     a.partials = c->d_part.p;
     a.model = model ? c->d_model.p : nullptr;
-    {
+    if (device_tables) a.tile_rot = tile_rot;
+    else {
         const int32_t *pairs = (const int32_t *)(c->h_stage.p + L.off_pairs);
         const tamcmc_multiplet *hm = (const tamcmc_multiplet *)(c->h_stage.p + L.off_mults);
         a.tile_rot = tamcmc::pick_tile_rot(hm + pairs[0], pairs[1] - pairs[0], a.x0, a.step, tb, ntiles);
@@ -251,11 +253,12 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, cons
     std::vector<int32_t> st_local;
     if (!status) { st_local.resize((size_t)B); status = st_local.data(); }
     // the red-giant model needs its device pre-step (mixed-mode solver, zeta) before the rows can be written
-    int rc = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID)
-                 ? tamcmc::rgb_stage_params(c, B, params, Nparams, plength, status, &per, &stride, &first_err)
+    const bool rgb = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID);
+    int rot = 0;
+    int rc = rgb ? tamcmc::rgb_stage_params(c, B, params, Nparams, plength, status, &per, &stride, &first_err, &rot)
                  : stage_params(c, model_id, B, params, Nparams, plength, status, &per, &stride, &first_err);
     if (rc) return rc;
-    rc = run_staged(c, B, StageLayout(B, stride, (size_t)B * per), stride, Tcoefs, p, logL, model);
+    rc = run_staged(c, B, StageLayout(B, stride, (size_t)B * per), stride, Tcoefs, p, logL, model, rgb, rot);
     if (rc) return rc;
     for (int b = 0; b < B; b++)
         if (status[b] != TAMCMC_OK) logL[b] = NAN;

@@ -7,7 +7,8 @@
 #define TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID 25
 
 namespace tamcmc {
-// Fills c->h_stage with the B variable-length tables (layout StageLayout(B, stride, B*per)); status[b] per vector.
+// Builds the B variable-length tables in the DEVICE staging block c->d_stage (layout StageLayout(B, stride, B*per)); status[b] per vector;
+// tile_rot = launch-order hint for k_loglike.
 int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Nparams, const int32_t *plength, int32_t *status,
-                     int *per_out, int *stride_out, int *first_err);
+                     int *per_out, int *stride_out, int *first_err, int *tile_rot_out);
 }  // namespace tamcmc

@@ -5,10 +5,10 @@
 //   device : ARMM mixed-mode solver -- scan p(nu)-g(nu) on the resol grid for sign changes, refine each on the
 //            fine local grid by inverse linear interpolation, keep true intersections        external/ARMM/solver_mm.cpp:340-443
 //            one workgroup per (parameter vector, p mode); sort + tolerance-unique per vector                     :586-593
-//   host   : + spline bias of the frequencies (cubic / Hermite, natural ends)            external/spline/src/spline.h:242-498
+//   device : + spline bias of the frequencies (coefficients from the host: cubic / Hermite, natural ends)   external/spline/src/spline.h:242-498
 //   device : zeta function at the mixed modes and its normalisation, max over a 4-year-resolution grid of the
 //            sum over all (p, g) pairs (collapsed to one term per p mode, see ksi_sum)   external/ARMM/bump_DP.cpp:46-78, :125-188
-//   host   : mixed-mode heights / widths / rotational splittings, windows, table rows    bump_DP.cpp:203-254, :531-547; models.cpp:4867-5000
+//   device : mixed-mode heights / widths / rotational splittings, windows, table rows    bump_DP.cpp:203-254, :531-547; models.cpp:4867-5000
 //
 // The reference runs the solver for every (p mode, g mode) pair whose g mode lies within the search zone of the p mode.  g(nu)
 // depends on nu_g only through tan(pi 1e6 (1/nu - 1/nu_g)/DPl), which is the same function for every g mode of the ladder
@@ -43,6 +43,18 @@ struct Prep {  // one parameter vector's solver inputs
     int ig0[MAXP];                 // first g mode inside the zone of p mode ip, -1: none (the reference skips the pair)
     double nu_p[MAXP], dnu_loc[MAXP], dnup[MAXP];
     double Dnu_p, DPl, alpha, q, zone, resol, fact, keep_lo, keep_hi;
+};
+
+constexpr int MAXL = 32;       // modes per degree listed in the parameter vector
+constexpr int MAXNODE = 16;    // nodes of the bias spline
+constexpr int CAP1 = 400;      // mixed modes per vector that get a table row
+
+struct RowIn {  // everything the row builder needs besides the solver's output (host-filled, one per vector)
+    int Nfl0, Nfl2, Nfl3, lmax, do_amp, bias_n, status, pad;
+    double fl0[MAXL], Wl0[MAXL], Hl0[MAXL], fl2[MAXL], fl3[MAXL];
+    double g[6], Vl[4], V[4][7];
+    double eta0, asym, trunc_c, Hfactor, Wfactor, rot_env, rot_core, a2, a3, a4, a5, a6, fmin, fmax;
+    double sx[MAXNODE], sy[MAXNODE], sb[MAXNODE], sc[MAXNODE], sd[MAXNODE], sc0;  // spline coefficients (host-computed), bias_n nodes
 };
 
 __host__ __device__ inline double nu_g_of(const Prep &p, int ig) { return 1e6 / (((double)(p.ng_min + ig) + p.alpha) * p.DPl); }
@@ -173,7 +185,7 @@ __global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sol
 }
 
 // One workgroup per vector: bitonic sort of its solutions, then std::unique with |a-b| <= 2 resol (solver_mm.cpp:586-593).
-__global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, double *sols, int *nsol) {
+__global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, const RowIn *rows_in, double *sols, int *nsol, double *fl1) {
     const int b = blockIdx.x, tid = threadIdx.x;
     __shared__ double s[MAXSOL];
     if (nsol[b] > MAXSOL) return;  // overflow flag: left for the host
@@ -198,6 +210,25 @@ __global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, doub
         for (int i = 0; i < n; i++)
             if (m == 0 || !(fabs(sols[(size_t)b * MAXSOL + m - 1] - s[i]) <= tol)) sols[(size_t)b * MAXSOL + m++] = s[i];
         nsol[b] = m;
+        s[0] = (double)m;
+    }
+    __syncthreads();
+    // frequency bias of the mixed modes: spline through the (fref, ferr) nodes (models.cpp:4833-4842, :4873-4880; spline.h:476-498)
+    const RowIn &R = rows_in[b];
+    const int m = (int)s[0];
+    for (int i = tid; i < m; i += WG) {
+        const double v = sols[(size_t)b * MAXSOL + i];
+        double bias = 0;
+        if (R.bias_n >= 3) {
+            const int nn = R.bias_n;
+            int idx = 0;
+            while (idx + 1 < nn && R.sx[idx + 1] <= v) idx++;
+            const double h = v - R.sx[idx];
+            if (v < R.sx[0]) bias = (R.sc0 * h + R.sb[0]) * h + R.sy[0];
+            else if (v > R.sx[nn - 1]) bias = (R.sc[nn - 1] * h + R.sb[nn - 1]) * h + R.sy[nn - 1];
+            else bias = ((R.sd[idx] * h + R.sc[idx]) * h + R.sb[idx]) * h + R.sy[idx];
+        }
+        fl1[(size_t)b * MAXSOL + i] = v + bias;
     }
 }
 
@@ -243,6 +274,87 @@ __global__ void __launch_bounds__(WG) k_zeta(const Prep *preps, const double *fl
     }
     for (int off = 32; off >= 1; off >>= 1) best = fmax(best, __shfl_down(best, off, 64));
     if ((tid & 63) == 0 && best > 0) atomicMax(&norm_bits[b], (unsigned long long)__double_as_longlong(best));  // positive doubles order as integers
+}
+
+// One workgroup per vector: the table rows (l=0 list, mixed modes, l=2, l=3 lists) written into the likelihood kernel's input block,
+// in the reference's accumulation order (models.cpp:4915-5000); mixed-mode scalars: bump_DP.cpp:203-254, :531-547.
+__global__ void __launch_bounds__(WG) k_rgb_rows(const Prep *preps, const RowIn *rows_in, const mt::PolyTab *poly, const double *fl1, const int *n1,
+                                                 const double *ksi, const unsigned long long *norm_bits, double x_first, double x_last, long Nx,
+                                                 double step, int per, tamcmc_multiplet *mults, int *pairs, int *status) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const RowIn &R = rows_in[b];
+    __shared__ double s_fi[MAXL + 4], s_hi[MAXL + 4];
+    __shared__ int s_st;
+    if (tid == 0) s_st = (R.status != 0 || preps[b].status != 0) ? (R.status ? R.status : preps[b].status) : 0;
+    const int ni = R.Nfl0 + 4;
+    if (tid < ni) {  // l=0 heights on a grid that falls to zero beyond the observed orders (models.cpp:4884-4897)
+        double f, h;
+        if (tid == 0) { f = R.fmin * 0.6; h = 0; }
+        else if (tid == 1) { f = R.fmin * 0.8; h = R.Hl0[0] / 4; }
+        else if (tid == ni - 2) { f = R.fmax * 1.2; h = R.Hl0[R.Nfl0 - 1] / 4; }
+        else if (tid == ni - 1) { f = R.fmax * 1.4; h = 0; }
+        else { f = R.fl0[tid - 2]; h = R.Hl0[tid - 2]; }
+        s_fi[tid] = f; s_hi[tid] = h;
+    }
+    __syncthreads();
+    int N1 = n1[b];
+    if (s_st == 0 && (N1 > CAP1 || N1 < 0)) { if (tid == 0) s_st = TAMCMC_ERR_BAD_ARG; N1 = 0; }
+    __syncthreads();
+    const bool ok = (s_st == 0);
+    const int total = ok ? R.Nfl0 + N1 + R.Nfl2 + R.Nfl3 : 0;
+    double norm = __longlong_as_double((long long)norm_bits[b]);
+    const double PIL = 3.14159265358979323846;
+    for (int k = tid; k < total; k += WG) {
+        int l;
+        double f, H, W, a[7] = {0, 0, 0, 0, 0, 0, 0}, eta0 = R.eta0;
+        if (k < R.Nfl0) { l = 0; f = R.fl0[k]; H = R.Hl0[k]; W = R.Wl0[k]; eta0 = 0.0; }
+        else if (k < R.Nfl0 + N1) {
+            l = 1;
+            const int i = k - R.Nfl0;
+            f = fl1[(size_t)b * MAXSOL + i];
+            double z = ksi[(size_t)b * MAXSOL + i] / norm;
+            if (z > 1) z = 1;
+            double hr = sqrt(1. - R.Hfactor * z);
+            if (hr > -1e-5 && hr < 1e-5) hr = 1e-10;
+            const double t = mt::lin_interpol(s_fi, s_hi, ni, f);
+            const double Hp = t < 0 ? 0.0 : fabs(t);
+            H = fabs(hr * (Hp * R.Vl[1]));
+            W = mt::lin_interpol(R.fl0, R.Wl0, R.Nfl0, f) * (1. - R.Wfactor * z) / sqrt(hr);
+            a[1] = fabs(z * (R.rot_core / 2 - R.rot_env) + R.rot_env);
+        } else {
+            const bool is2 = k < R.Nfl0 + N1 + R.Nfl2;
+            l = is2 ? 2 : 3;
+            f = is2 ? R.fl2[k - R.Nfl0 - N1] : R.fl3[k - R.Nfl0 - N1 - R.Nfl2];
+            const double lnGamma0 = R.g[2] * log(f / R.g[0]) + log(R.g[3]);
+            const double e = 2. * log(f / R.g[1]) / log(R.g[4] / R.g[0]);
+            W = exp(lnGamma0 + -log(R.g[5]) / (1. + e * e));
+            H = mt::lin_interpol(R.fl0, R.Hl0, R.Nfl0, f);
+            H = R.do_amp ? fabs(H / (PIL * W) * R.Vl[l]) : fabs(H * R.Vl[l]);
+            a[1] = R.rot_env; a[2] = R.a2; a[3] = R.a3; a[4] = R.a4;
+            if (!is2) { a[5] = R.a5; a[6] = R.a6; }
+        }
+        tamcmc_multiplet *r = &mults[(size_t)b * per + k];
+        int i0 = 0, i1 = 0;
+        const int rs = mt::set_imin_imax(x_first, x_last, Nx, l, f, W, a[1], R.trunc_c, step, &i0, &i1);
+        if (rs) { s_st = rs; continue; }
+        r->l = l; r->i0 = i0; r->i1 = i1; r->flags = 0; r->fc = f; r->gamma = W; r->asym = R.asym;
+        for (int q = 0; q < 7; q++) { r->nu[q] = 0; r->hv[q] = 0; }
+        for (int m = -l; m <= l; m++) {
+            r->nu[m + l] = l == 0 ? f : mt::nu_nlm_aj(*poly, f, a, eta0, l, m);
+            r->hv[m + l] = H * R.V[l][m + l];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool good = (s_st == 0);
+        pairs[2 * b] = b * per;
+        pairs[2 * b + 1] = good ? b * per + total : b * per;
+        status[b] = s_st;
+    }
+}
+
+__global__ void k_fill_poly_rgb(mt::PolyTab *t) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) mt::fill_poly(*t);
 }
 
 // ---------------------------------------------------------------- host side
@@ -428,153 +540,112 @@ int unpack(const double *p, const int32_t *pl, double step, Unpacked &u, Prep &P
 }  // namespace
 }  // namespace rgb
 
-// Builds the B tables of model 25 straight into the pinned staging block (same layout as capi.hip's stage_params).
+// Builds the B tables of model 25 in the DEVICE staging block c->d_stage (layout StageLayout(B, stride, B*per), the one run_staged
+// launches on); only the small header (counts, noise rows) goes through the host block.  One stream synchronisation (for the
+// per-vector status); no table data crosses PCIe.
 int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Nparams, const int32_t *plength, int32_t *status,
-                     int *per_out, int *stride_out, int *first_err) {
+                     int *per_out, int *stride_out, int *first_err, int *tile_rot_out) {
     using namespace rgb;
     const double *hx = c->hx.data();
     const int64_t Nx = c->Nx;
     const double step = hx[2] - hx[1];  // models.cpp:4719
     const int stride = plength[8] > 0 ? plength[8] : 1;
     if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
+    if (plength[2] > MAXL || plength[4] > MAXL || plength[5] > MAXL) return TAMCMC_ERR_BAD_ARG;
     std::vector<Unpacked> U((size_t)B);
     std::vector<Prep> P((size_t)B);
+    std::vector<RowIn> R((size_t)B);
+    const int per = plength[2] + plength[4] + plength[5] + CAP1;
+    const StageLayout L(B, stride, (size_t)B * per);
+    HIPCHK(c, c->h_stage.reserve(L.off_mults));
+    HIPCHK(c, c->d_stage.reserve(L.bytes));
+    unsigned char *h = c->h_stage.p;
+    int32_t *h_nh = (int32_t *)(h + L.off_nh), *h_nn = (int32_t *)(h + L.off_nn);
+    double *h_noise = (double *)(h + L.off_noise);
+    double fmin_all = 1e300;
     for (int b = 0; b < B; b++) {
-        status[b] = unpack(params + (size_t)b * Nparams, plength, step, U[(size_t)b], P[(size_t)b]);
-        P[(size_t)b].status = status[b];
+        const double *p = params + (size_t)b * Nparams;
+        Unpacked &u = U[(size_t)b];
+        RowIn &ri = R[(size_t)b];
+        std::memset(&ri, 0, sizeof ri);
+        int st = unpack(p, plength, step, u, P[(size_t)b]);
+        if (st == TAMCMC_OK && u.bias_type != 0) {
+            Spline s;
+            if (u.Nferr > MAXNODE || !s.set(p + u.o1 + 8, p + u.o1 + 8 + u.Nferr, u.Nferr, u.bias_type == 1 ? 1 : 2)) st = TAMCMC_ERR_BAD_ARG;
+            else {
+                ri.bias_n = u.Nferr;
+                for (int i = 0; i < u.Nferr; i++) {
+                    ri.sx[i] = s.x[(size_t)i]; ri.sy[i] = s.y[(size_t)i]; ri.sb[i] = s.b[(size_t)i]; ri.sc[i] = s.c[(size_t)i]; ri.sd[i] = s.d[(size_t)i];
+                }
+                ri.sc0 = s.c0;
+            }
+        }
+        status[b] = st;
+        P[(size_t)b].status = st;
+        ri.status = st;
+        if (st == TAMCMC_OK) {
+            ri.Nfl0 = u.Nfl0; ri.Nfl2 = u.Nfl2; ri.Nfl3 = u.Nfl3; ri.lmax = u.lmax; ri.do_amp = u.do_amp ? 1 : 0;
+            const double *fl0 = p + u.Nmax + u.lmax;
+            for (int k = 0; k < u.Nfl0; k++) { ri.fl0[k] = fl0[k]; ri.Wl0[k] = u.Wl0[(size_t)k]; ri.Hl0[k] = u.Hl0[(size_t)k]; }
+            for (int k = 0; k < u.Nfl2; k++) ri.fl2[k] = std::fabs(p[u.o1 + u.Nfl1 + k]);
+            for (int k = 0; k < u.Nfl3; k++) ri.fl3[k] = std::fabs(p[u.o1 + u.Nfl1 + u.Nfl2 + k]);
+            for (int k = 0; k < 6; k++) ri.g[k] = u.g[k];
+            for (int l = 0; l < 4; l++) ri.Vl[l] = u.Vl[l];
+            ri.V[0][0] = 1.0;
+            for (int l = 1; l <= u.lmax; l++) mt::amplitude_ratio(l, u.inclination, ri.V[l]);
+            ri.eta0 = u.eta0; ri.asym = u.asym; ri.trunc_c = u.trunc_c; ri.Hfactor = u.Hfactor; ri.Wfactor = u.Wfactor;
+            ri.rot_env = u.rot_env; ri.rot_core = u.rot_core;
+            ri.a2 = p[u.os + 2]; ri.a3 = p[u.os + 4]; ri.a4 = p[u.os + 5]; ri.a5 = p[u.os + 6]; ri.a6 = p[u.os + 7];
+            ri.fmin = u.fmin; ri.fmax = u.fmax;
+            if (u.fmin < fmin_all) fmin_all = u.fmin;
+            for (int k = 0; k < u.Nnoise; k++) h_noise[(size_t)b * stride + k] = std::fabs(p[u.onoise + k]);
+            h_nh[b] = (u.Nnoise - 1) / 3; h_nn[b] = u.Nnoise;
+        } else {
+            h_noise[(size_t)b * stride] = 1.0;  // placeholder row; logL[b] is overwritten with NaN
+            h_nh[b] = 0; h_nn[b] = 1;
+        }
     }
     hipStream_t st = c->stream;
-    // ---- device: solver
-    const size_t bytes_prep = (size_t)B * sizeof(Prep), nsolbuf = (size_t)B * MAXSOL;
-    HIPCHK(c, c->d_rgb.reserve(bytes_prep + nsolbuf * 3 * sizeof(double) + (size_t)B * (2 * sizeof(int) + sizeof(unsigned long long)) + 64));
+    // ---- device workspace
+    const size_t bytes_prep = ((size_t)B * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)B * sizeof(RowIn) + 15) & ~(size_t)15;
+    const size_t nsolbuf = (size_t)B * MAXSOL;
+    HIPCHK(c, c->d_rgb.reserve(bytes_prep + bytes_rows + nsolbuf * 3 * sizeof(double) + (size_t)B * (3 * sizeof(int) + sizeof(unsigned long long)) + 64));
     unsigned char *base = c->d_rgb.p;
     Prep *d_prep = (Prep *)base;
-    double *d_sols = (double *)(base + ((bytes_prep + 15) & ~(size_t)15));
+    RowIn *d_rows = (RowIn *)(base + bytes_prep);
+    double *d_sols = (double *)(base + bytes_prep + bytes_rows);
     double *d_fl1 = d_sols + nsolbuf, *d_ksi = d_fl1 + nsolbuf;
     unsigned long long *d_norm = (unsigned long long *)(d_ksi + nsolbuf);
-    int *d_nsol = (int *)(d_norm + B), *d_n1 = d_nsol + B;
-    HIPCHK(c, hipMemcpyAsync(d_prep, P.data(), bytes_prep, hipMemcpyHostToDevice, st));
+    int *d_nsol = (int *)(d_norm + B), *d_status = d_nsol + B;
+    if (!c->poly_ready) {  // Pslm/Qlm tables in device memory (shared with the finite-difference builder)
+        HIPCHK(c, c->d_poly.reserve(sizeof(mt::PolyTab)));
+        hipLaunchKernelGGL(k_fill_poly_rgb, dim3(1), dim3(64), 0, st, (mt::PolyTab *)c->d_poly.p);
+        c->poly_ready = true;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage.p, L.off_mults, hipMemcpyHostToDevice, st));  // header only
+    HIPCHK(c, hipMemcpyAsync(d_prep, P.data(), (size_t)B * sizeof(Prep), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_rows, R.data(), (size_t)B * sizeof(RowIn), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(d_norm, 0, (size_t)B * (sizeof(unsigned long long) + 2 * sizeof(int)), st));
     hipLaunchKernelGGL(k_armm_scan, dim3(MAXP * SEG, B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
-    hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
-    HIPCHK(c, hipGetLastError());
-    std::vector<int> n1((size_t)B);
-    std::vector<double> fl1(nsolbuf), ksi(nsolbuf);
-    HIPCHK(c, hipMemcpyAsync(n1.data(), d_nsol, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(fl1.data(), d_sols, nsolbuf * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    // ---- host: frequency bias (models.cpp:4833-4842, :4873-4880)
-    for (int b = 0; b < B; b++) {
-        if (status[b] != TAMCMC_OK) { n1[(size_t)b] = 0; continue; }
-        if (n1[(size_t)b] > MAXSOL) { status[b] = TAMCMC_ERR_BAD_ARG; P[(size_t)b].status = status[b]; n1[(size_t)b] = 0; continue; }
-        const Unpacked &u = U[(size_t)b];
-        if (u.bias_type != 0) {
-            const double *p = params + (size_t)b * Nparams;
-            Spline s;
-            if (!s.set(p + u.o1 + 8, p + u.o1 + 8 + u.Nferr, u.Nferr, u.bias_type == 1 ? 1 : 2)) { status[b] = TAMCMC_ERR_BAD_ARG; n1[(size_t)b] = 0; continue; }
-            for (int i = 0; i < n1[(size_t)b]; i++) fl1[(size_t)b * MAXSOL + i] += s(fl1[(size_t)b * MAXSOL + i]);
-        }
-    }
-    // ---- device: zeta
-    HIPCHK(c, hipMemcpyAsync(d_fl1, fl1.data(), nsolbuf * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_n1, n1.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_rows, d_sols, d_nsol, d_fl1);
     const int chunks = 64;
-    hipLaunchKernelGGL(k_zeta, dim3(chunks, B), dim3(WG), 0, st, d_prep, d_fl1, d_n1, d_ksi, d_norm, chunks);
+    hipLaunchKernelGGL(k_zeta, dim3(chunks, B), dim3(WG), 0, st, d_prep, d_fl1, d_nsol, d_ksi, d_norm, chunks);
+    hipLaunchKernelGGL(k_rgb_rows, dim3(B), dim3(WG), 0, st, d_prep, d_rows, (const mt::PolyTab *)c->d_poly.p, d_fl1, d_nsol, d_ksi, d_norm, hx[0],
+                       hx[Nx - 1], (long)Nx, step, per, (tamcmc_multiplet *)(c->d_stage.p + L.off_mults), (int *)(c->d_stage.p + L.off_pairs), d_status);
     HIPCHK(c, hipGetLastError());
-    std::vector<unsigned long long> nb((size_t)B);
-    HIPCHK(c, hipMemcpyAsync(ksi.data(), d_ksi, nsolbuf * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(nb.data(), d_norm, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    std::vector<int> dst((size_t)B);
+    HIPCHK(c, hipMemcpyAsync(dst.data(), d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    // ---- host: rows
-    int per = 1;
-    for (int b = 0; b < B; b++)
-        if (status[b] == TAMCMC_OK) per = std::max(per, U[(size_t)b].Nfl0 + n1[(size_t)b] + U[(size_t)b].Nfl2 + U[(size_t)b].Nfl3);
-    const StageLayout L(B, stride, (size_t)B * per);
-    HIPCHK(c, c->h_stage.reserve(L.bytes));
-    unsigned char *h = c->h_stage.p;
-    int32_t *pairs = (int32_t *)(h + L.off_pairs), *h_nh = (int32_t *)(h + L.off_nh), *h_nn = (int32_t *)(h + L.off_nn);
-    double *h_noise = (double *)(h + L.off_noise);
-    tamcmc_multiplet *h_mults = (tamcmc_multiplet *)(h + L.off_mults);
-    const mt::PolyTab &T = poly_table();
-    for (int b = 0; b < B; b++) {
-        int n = 0, stb = status[b];
-        tamcmc_multiplet *rows = h_mults + (size_t)b * per;
-        if (stb == TAMCMC_OK) {
-            const Unpacked &u = U[(size_t)b];
-            const double *p = params + (size_t)b * Nparams;
-            const double *fl0 = p + u.Nmax + u.lmax;
-            double norm;
-            std::memcpy(&norm, &nb[(size_t)b], sizeof norm);
-            double V[4][7] = {{1, 0, 0, 0, 0, 0, 0}};
-            for (int l = 1; l <= u.lmax; l++) mt::amplitude_ratio(l, u.inclination, V[l]);
-            auto add = [&](int l, double f, double H, double W, const double a[7], double eta0) {
-                tamcmc_multiplet *r = &rows[n];
-                int i0 = 0, i1 = 0;
-                const int rs = mt::set_imin_imax(hx[0], hx[Nx - 1], Nx, l, f, W, a[1], u.trunc_c, step, &i0, &i1);
-                if (rs) { stb = rs; return; }
-                r->l = l; r->i0 = i0; r->i1 = i1; r->flags = 0; r->fc = f; r->gamma = W; r->asym = u.asym;
-                for (int k = 0; k < 7; k++) { r->nu[k] = 0; r->hv[k] = 0; }
-                for (int m = -l; m <= l; m++) {
-                    r->nu[m + l] = l == 0 ? f : mt::nu_nlm_aj(T, f, a, eta0, l, m);
-                    r->hv[m + l] = H * V[l][m + l];
-                }
-                n++;
-            };
-            const double a0[7] = {0, 0, 0, 0, 0, 0, 0};
-            for (int k = 0; k < u.Nfl0 && stb == TAMCMC_OK; k++) add(0, fl0[k], u.Hl0[(size_t)k], u.Wl0[(size_t)k], a0, 0.0);
-            // mixed modes: zeta -> height ratio, width, splitting (bump_DP.cpp:203-254, :531-547; models.cpp:4882-4906)
-            const int ni = u.Nfl0 + 4;
-            std::vector<double> fi((size_t)ni), hi((size_t)ni);
-            fi[0] = u.fmin * 0.6; fi[1] = u.fmin * 0.8; fi[(size_t)ni - 2] = u.fmax * 1.2; fi[(size_t)ni - 1] = u.fmax * 1.4;
-            hi[0] = 0; hi[1] = u.Hl0[0] / 4; hi[(size_t)ni - 2] = u.Hl0[(size_t)u.Nmax - 1] / 4; hi[(size_t)ni - 1] = 0;
-            for (int j = 0; j < u.Nfl0; j++) { fi[(size_t)j + 2] = fl0[j]; hi[(size_t)j + 2] = u.Hl0[(size_t)j]; }
-            for (int i = 0; i < n1[(size_t)b] && stb == TAMCMC_OK; i++) {
-                const double f = fl1[(size_t)b * MAXSOL + i];
-                double z = ksi[(size_t)b * MAXSOL + i] / norm;
-                if (z > 1) z = 1;
-                double hr = std::sqrt(1. - u.Hfactor * z);
-                if (hr > -1e-5 && hr < 1e-5) hr = 1e-10;
-                const double t = mt::lin_interpol(fi.data(), hi.data(), ni, f);
-                const double Hp = t < 0 ? 0.0 : std::fabs(t);
-                const double H = std::fabs(hr * (Hp * u.Vl[1]));
-                const double W = mt::lin_interpol(fl0, u.Wl0.data(), u.Nfl0, f) * (1. - u.Wfactor * z) / std::sqrt(hr);
-                const double a1[7] = {0, std::fabs(z * (u.rot_core / 2 - u.rot_env) + u.rot_env), 0, 0, 0, 0, 0};
-                add(1, f, H, W, a1, u.eta0);
-            }
-            const double a2[7] = {0, u.rot_env, p[u.os + 2], p[u.os + 4], p[u.os + 5], 0, 0};
-            for (int k = 0; k < u.Nfl2 && stb == TAMCMC_OK; k++) {
-                const double f = std::fabs(p[u.o1 + u.Nfl1 + k]), W = app_width(u.g, f);
-                double H = mt::lin_interpol(fl0, u.Hl0.data(), u.Nfl0, f);
-                H = u.do_amp ? (double)fabsl(H / ((long double)M_PI * W) * u.Vl[2]) : std::fabs(H * u.Vl[2]);
-                add(2, f, H, W, a2, u.eta0);
-            }
-            const double a3[7] = {0, u.rot_env, p[u.os + 2], p[u.os + 4], p[u.os + 5], p[u.os + 6], p[u.os + 7]};
-            for (int k = 0; k < u.Nfl3 && stb == TAMCMC_OK; k++) {
-                const double f = std::fabs(p[u.o1 + u.Nfl1 + u.Nfl2 + k]), W = app_width(u.g, f);
-                double H = mt::lin_interpol(fl0, u.Hl0.data(), u.Nfl0, f);
-                H = u.do_amp ? (double)fabsl(H / ((long double)M_PI * W) * u.Vl[3]) : std::fabs(H * u.Vl[3]);
-                add(3, f, H, W, a3, u.eta0);
-            }
-        }
-        status[b] = stb;
-        int nh = 0, nn = 1;
-        if (stb == TAMCMC_OK) {
-            const Unpacked &u = U[(size_t)b];
-            for (int k = 0; k < u.Nnoise; k++) h_noise[(size_t)b * stride + k] = std::fabs(params[(size_t)b * Nparams + u.onoise + k]);
-            nh = (u.Nnoise - 1) / 3; nn = u.Nnoise;
-        } else {
-            n = 0;
-            h_noise[(size_t)b * stride] = 1.0;  // placeholder row; logL[b] is overwritten with NaN
-        }
-        pairs[2 * b] = (int32_t)((size_t)b * per);
-        pairs[2 * b + 1] = (int32_t)((size_t)b * per + n);
-        h_nh[b] = nh; h_nn[b] = nn;
-    }
     *first_err = TAMCMC_OK;
-    for (int b = 0; b < B; b++)
+    for (int b = 0; b < B; b++) {
+        if (status[b] == TAMCMC_OK) status[b] = dst[(size_t)b];
         if (status[b] != TAMCMC_OK && *first_err == TAMCMC_OK) *first_err = status[b];
+    }
     *per_out = per;
     *stride_out = stride;
+    const int tb = tile_bins(c->wgs, c->K), ntiles = (int)((Nx + tb - 1) / tb);
+    double t = (fmin_all < 1e299) ? (fmin_all - hx[0]) / (hx[1] - hx[0]) / (double)tb - 3.0 : 0.0;  // first near-field tile: a little below the lowest radial mode
+    *tile_rot_out = (t > 0 && t < ntiles) ? (int)t : 0;
     return TAMCMC_OK;
 }
 
