@@ -43,6 +43,8 @@ extern "C" {
 #define TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 25 /* model_RGB_asympt_aj_AppWidth_HarveyLike_v4, models.cpp:4684: only through
                                                     tamcmc_hip_loglike_params_batch (its table needs the device pre-step:
                                                     ARMM mixed-mode solver + zeta function, csrc/rgb_prestep.hip) */
+#define TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4 27 /* model_RGB_asympt_aj_CteWidth_HarveyLike_v4, models.cpp:4334: same path, one
+                                                    constant width for the l=0,2,3 modes */
 
 /* ---------------- arithmetic modes ---------------- */
 /* STRICT: per-bin operation order of the reference (IEEE divides, no FMA contraction): the model row is

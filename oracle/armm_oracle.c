@@ -351,7 +351,10 @@ static double app_width(const double g[6], double f) {  /* Appourchaux et al. 20
     return exp(lnGamma0 + lnLorentz);
 }
 
-int orc_rgb_v4_modes(const double *params, const int *pl, double step, orc_rgb_modes *out) {
+/* cte_width = 0: model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (models.cpp:4684-5079)
+ * cte_width = 1: model_RGB_asympt_aj_CteWidth_HarveyLike_v4 (models.cpp:4334-4682): one width parameter, every l=0/2/3 width is that
+ *                constant (:4407), and the fmin - Dnu_p >= 0 requirement sits inside the model_type == 0 branch only (:4453-4466). */
+static int rgb_v4_modes(const double *params, const int *pl, double step, int cte_width, orc_rgb_modes *out) {
     memset(out, 0, sizeof *out);
     const long double pi = M_PI;
     const int Nmax = pl[0], lmax = pl[1], Nfl0 = pl[2], Nfl1 = pl[3], Nfl2 = pl[4], Nfl3 = pl[5], Nsplit = pl[6], Nwidth = pl[7], Nnoise = pl[8],
@@ -361,12 +364,12 @@ int orc_rgb_v4_modes(const double *params, const int *pl, double step, orc_rgb_m
     const int do_amp = params[ocfg + 1] != 0;
     const double model_type = params[ocfg + 3], bias_type = params[ocfg + 4];
     const int Nferr = (int)params[ocfg + 5];
-    if (Nmax < 2 || Nmax != Nfl0 || Nferr < 0 || Nfl1 != 8 + 2 * Nferr) return ORC_ERR_BAD_ARG;
-    double g[6];
-    for (int k = 0; k < 6; k++) g[k] = fabs(params[Nmax + lmax + Nf + Nsplit + k]);
+    if (Nmax < 2 || Nmax != Nfl0 || Nferr < 0 || Nfl1 != 8 + 2 * Nferr || Nwidth < (cte_width ? 1 : 6)) return ORC_ERR_BAD_ARG;
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < (cte_width ? 1 : 6); k++) g[k] = fabs(params[Nmax + lmax + Nf + Nsplit + k]);
     const double *fl0 = params + Nmax + lmax;
     double *Wl0 = dalloc(Nmax), *Hl0 = dalloc(Nmax);
-    for (int n = 0; n < Nmax; n++) Wl0[n] = app_width(g, fl0[n]);
+    for (int n = 0; n < Nmax; n++) Wl0[n] = cte_width ? g[0] : app_width(g, fl0[n]);
     for (int n = 0; n < Nmax; n++) Hl0[n] = do_amp ? (double)fabsl(params[n] * (1. / Wl0[n] / pi)) : fabs(params[n]);
     const int o1 = Nmax + lmax + Nfl0;
     const double delta0l = params[o1], DPl = fabs(params[o1 + 1]), alpha_g = fabs(params[o1 + 2]), q_star = fabs(params[o1 + 3]);
@@ -391,7 +394,9 @@ int orc_rgb_v4_modes(const double *params, const int *pl, double step, orc_rgb_m
     const double epsilon_p = rfit[1] / Dnu_p - n0;
     int rc = ORC_OK;
     orc_eigensols sol;
-    if (fmin - Dnu_p < 0) rc = ORC_ERR_BAD_ARG;  /* the reference exits: infinite g-mode density (:4851-4857) */
+    /* the reference exits: infinite g-mode density (:4851-4857).  The constant-width variant only tests this when model_type == 0;
+     * with model_type != 0 its solver would be handed a zero lower bound (1e6/(0*DPl) g modes), which is refused here as well. */
+    if (fmin - Dnu_p < 0) rc = ORC_ERR_BAD_ARG;
     else if (model_type == 0) rc = orc_armm_solve_O2p(Dnu_p, epsilon_p, 1, delta0l, 0, 0., DPl, alpha_g, q_star, fmin - Dnu_p, fmax + Dnu_p, step, &sol);
     else rc = orc_armm_solve_O2from_l0(fl0, Nfl0, 1, delta0l, DPl, alpha_g, q_star, step, fmin, fmax, &sol);
     if (rc != ORC_OK) { free(Wl0); free(Hl0); if (have_bias) spline_free(&bias); return rc; }
@@ -430,13 +435,16 @@ int orc_rgb_v4_modes(const double *params, const int *pl, double step, orc_rgb_m
     return ORC_OK;
 }
 
+int orc_rgb_v4_modes(const double *params, const int *pl, double step, orc_rgb_modes *out) { return rgb_v4_modes(params, pl, step, 0, out); }
+int orc_rgb_v4_cte_modes(const double *params, const int *pl, double step, orc_rgb_modes *out) { return rgb_v4_modes(params, pl, step, 1, out); }
+
 void orc_rgb_modes_free(orc_rgb_modes *m) {
     if (!m) return;
     free(m->fl0); free(m->Wl0); free(m->Hl0); free(m->fl1); free(m->Wl1); free(m->Hl1); free(m->a1_l1); free(m->ksi);
     memset(m, 0, sizeof *m);
 }
 
-int orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(const double *params, const int *pl, const double *x, long Nx, double *model) {
+static int rgb_v4_model(const double *params, const int *pl, const double *x, long Nx, double *model, int cte_width) {
     if (Nx < 3) return ORC_ERR_BAD_ARG;
     const long double pi = M_PI;
     const double step = x[2] - x[1];
@@ -447,7 +455,7 @@ int orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(const double *params, const i
     const double trunc_c = params[ocfg];
     const int do_amp = params[ocfg + 1] != 0;
     orc_rgb_modes md;
-    int rc = orc_rgb_v4_modes(params, pl, step, &md);
+    int rc = rgb_v4_modes(params, pl, step, cte_width, &md);
     if (rc != ORC_OK) return rc;
     const double inclination = fabs(params[Nmax + lmax + Nf + Nsplit + Nwidth + Nnoise]);
     double r0[1] = {1.0}, r1[3], r2[5], r3[7];
@@ -468,14 +476,14 @@ int orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(const double *params, const i
                                             trunc_c);
     for (int n = 0; n < Nfl2 && rc == ORC_OK; n++) {
         const double fl2 = fabs(params[Nmax + lmax + Nfl0 + Nfl1 + n]);
-        const double W = app_width(md.g, fl2);
+        const double W = cte_width ? md.g[0] : app_width(md.g, fl2);  /* Cte: Wl0_all[n], all equal (:4561) */
         double H = orc_lin_interpol(md.fl0, md.Hl0, Nfl0, fl2);
         H = do_amp ? (double)fabsl(H / (pi * W) * Vl2) : fabs(H * Vl2);
         rc = orc_optimum_lorentzian_calc_aj(x, model, Nx, H, fl2, rot_env, a2_env, a3_env, a4_env, 0, 0, eta0, asym, W, 2, r2, step, trunc_c);
     }
     for (int n = 0; n < Nfl3 && rc == ORC_OK; n++) {
         const double fl3 = fabs(params[Nmax + lmax + Nfl0 + Nfl1 + Nfl2 + n]);
-        const double W = app_width(md.g, fl3);
+        const double W = cte_width ? md.g[0] : app_width(md.g, fl3);
         double H = orc_lin_interpol(md.fl0, md.Hl0, Nfl0, fl3);
         H = do_amp ? (double)fabsl(H / (pi * W) * Vl3) : fabs(H * Vl3);
         rc = orc_optimum_lorentzian_calc_aj(x, model, Nx, H, fl3, rot_env, a2_env, a3_env, a4_env, a5_env, a6_env, eta0, asym, W, 3, r3, step, trunc_c);
@@ -487,4 +495,12 @@ int orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(const double *params, const i
     orc_harvey_like(np, Nnoise, x, model, Nx, (Nnoise - 1) / 3);
     free(np);
     return ORC_OK;
+}
+
+int orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(const double *params, const int *pl, const double *x, long Nx, double *model) {
+    return rgb_v4_model(params, pl, x, Nx, model, 0);
+}
+
+int orc_model_RGB_asympt_aj_CteWidth_HarveyLike_v4(const double *params, const int *pl, const double *x, long Nx, double *model) {
+    return rgb_v4_model(params, pl, x, Nx, model, 1);
 }

@@ -582,6 +582,7 @@ int orc_call_model(int model_id, const double *params, const int *plength, const
     case ORC_MODEL_MS_LOCAL_BASIC: return orc_model_MS_local_basic(params, plength, x, Nx, model);
     case ORC_MODEL_MS_GLOBAL_AJ: return orc_model_MS_Global_aj_HarveyLike(params, plength, x, Nx, model);
     case ORC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4: return orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(params, plength, x, Nx, model);
+    case ORC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4: return orc_model_RGB_asympt_aj_CteWidth_HarveyLike_v4(params, plength, x, Nx, model);
     default: return ORC_ERR_BAD_MODEL;
     }
 }

@@ -42,6 +42,7 @@ extern "C" {
 #define ORC_MODEL_MS_LOCAL_BASIC 11
 #define ORC_MODEL_MS_GLOBAL_AJ 23
 #define ORC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 25
+#define ORC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4 27
 
 /* ---- scalar helpers ---- */
 long double orc_Pslm(int s, int l, int m);               /* acoefs.cpp:51-110 */
@@ -113,9 +114,12 @@ typedef struct orc_rgb_modes {  /* what the model function derives before it sum
     double g[6];                                /* |width-law parameters| */
 } orc_rgb_modes;
 int orc_rgb_v4_modes(const double *params, const int *plength, double step, orc_rgb_modes *out);
+int orc_rgb_v4_cte_modes(const double *params, const int *plength, double step, orc_rgb_modes *out);  /* constant-width variant */
 void orc_rgb_modes_free(orc_rgb_modes *m);
 int orc_model_RGB_asympt_aj_AppWidth_HarveyLike_v4(const double *params, const int *plength, const double *x, long Nx,
                                                    double *model);                                  /* models.cpp:4684-5079 */
+int orc_model_RGB_asympt_aj_CteWidth_HarveyLike_v4(const double *params, const int *plength, const double *x, long Nx,
+                                                   double *model);                                  /* models.cpp:4334-4682 */
 
 /* call_likelihood (model_def.cpp:390-419): chi22p / Tcoef */
 double orc_call_likelihood(const double *y, const double *model, long Nx, double likelihood_params, double Tcoef);

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libtamcmc_hip.so")
 OK = 0
 ERR_HIP, ERR_EMPTY_WINDOW, ERR_NAN_WINDOW, ERR_BAD_MODEL, ERR_BAD_ARG, ERR_NO_SPECTRUM, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
 MODEL_MS_GLOBAL_A1ETAA3_CLASSIC, MODEL_MS_LOCAL_BASIC, MODEL_MS_GLOBAL_AJ = 3, 11, 23
+MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4 = 27   # constant-width variant of 25, same path
 MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 = 25  # batched device path only (tamcmc_hip_loglike_params_batch): needs the ARMM pre-step
 PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_DIRECT = 0, 1, 2
 OPT_PRECISION, OPT_TIMING, OPT_BINS_PER_THREAD, OPT_WORKGROUP, OPT_FD_WINDOWED = 1, 2, 3, 4, 5

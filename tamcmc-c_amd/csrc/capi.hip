@@ -253,9 +253,9 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, cons
     std::vector<int32_t> st_local;
     if (!status) { st_local.resize((size_t)B); status = st_local.data(); }
     // the red-giant model needs its device pre-step (mixed-mode solver, zeta) before the rows can be written
-    const bool rgb = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID);
+    const bool rgb = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID || model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4_ID);
     int rot = 0;
-    int rc = rgb ? tamcmc::rgb_stage_params(c, B, params, Nparams, plength, status, &per, &stride, &first_err, &rot)
+    int rc = rgb ? tamcmc::rgb_stage_params(c, model_id, B, params, Nparams, plength, status, &per, &stride, &first_err, &rot)
                  : stage_params(c, model_id, B, params, Nparams, plength, status, &per, &stride, &first_err);
     if (rc) return rc;
     rc = run_staged(c, B, StageLayout(B, stride, (size_t)B * per), stride, Tcoefs, p, logL, model, rgb, rot);

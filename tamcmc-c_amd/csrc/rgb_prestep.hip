@@ -50,7 +50,7 @@ constexpr int MAXNODE = 16;    // nodes of the bias spline
 constexpr int CAP1 = 400;      // mixed modes per vector that get a table row
 
 struct RowIn {  // everything the row builder needs besides the solver's output (host-filled, one per vector)
-    int Nfl0, Nfl2, Nfl3, lmax, do_amp, bias_n, status, pad;
+    int Nfl0, Nfl2, Nfl3, lmax, do_amp, bias_n, status, cte_width;  // cte_width: id 27, every width is g[0]
     double fl0[MAXL], Wl0[MAXL], Hl0[MAXL], fl2[MAXL], fl3[MAXL];
     double g[6], Vl[4], V[4][7];
     double eta0, asym, trunc_c, Hfactor, Wfactor, rot_env, rot_core, a2, a3, a4, a5, a6, fmin, fmax;
@@ -325,9 +325,12 @@ __global__ void __launch_bounds__(WG) k_rgb_rows(const Prep *preps, const RowIn 
             const bool is2 = k < R.Nfl0 + N1 + R.Nfl2;
             l = is2 ? 2 : 3;
             f = is2 ? R.fl2[k - R.Nfl0 - N1] : R.fl3[k - R.Nfl0 - N1 - R.Nfl2];
-            const double lnGamma0 = R.g[2] * log(f / R.g[0]) + log(R.g[3]);
-            const double e = 2. * log(f / R.g[1]) / log(R.g[4] / R.g[0]);
-            W = exp(lnGamma0 + -log(R.g[5]) / (1. + e * e));
+            if (R.cte_width) W = R.g[0];  // models.cpp:4561, :4582
+            else {
+                const double lnGamma0 = R.g[2] * log(f / R.g[0]) + log(R.g[3]);
+                const double e = 2. * log(f / R.g[1]) / log(R.g[4] / R.g[0]);
+                W = exp(lnGamma0 + -log(R.g[5]) / (1. + e * e));
+            }
             H = mt::lin_interpol(R.fl0, R.Hl0, R.Nfl0, f);
             H = R.do_amp ? fabs(H / (PIL * W) * R.Vl[l]) : fabs(H * R.Vl[l]);
             a[1] = R.rot_env; a[2] = R.a2; a[3] = R.a3; a[4] = R.a4;
@@ -431,8 +434,9 @@ double app_width(const double g[6], double f) {  // models.cpp:4788-4794
     return std::exp(lnGamma0 + -std::log(g[5]) / (1. + std::pow(e, 2)));
 }
 
-// models.cpp:4727-4866 + solver_mm.cpp:470-555 / :624-705 (everything before the pair loop)
-int unpack(const double *p, const int32_t *pl, double step, Unpacked &u, Prep &P) {
+// models.cpp:4727-4866 (id 25) / :4377-4470 (id 27, cte_width: one width parameter, Wl0 constant, :4407) + solver_mm.cpp:470-555 /
+// :624-705 (everything before the pair loop)
+int unpack(const double *p, const int32_t *pl, double step, bool cte_width, Unpacked &u, Prep &P) {
     const long double pi = M_PI;
     std::memset(&P, 0, sizeof P);
     u.Nmax = pl[0]; u.lmax = pl[1]; u.Nfl0 = pl[2]; u.Nfl1 = pl[3]; u.Nfl2 = pl[4]; u.Nfl3 = pl[5];
@@ -448,11 +452,12 @@ int unpack(const double *p, const int32_t *pl, double step, Unpacked &u, Prep &P
     u.model_type = p[u.ocfg + 3];
     u.bias_type = p[u.ocfg + 4];
     u.Nferr = (int)p[u.ocfg + 5];
-    if (u.Nmax < 2 || u.Nmax != u.Nfl0 || u.Nferr < 0 || u.Nfl1 != 8 + 2 * u.Nferr || Nwidth < 6 || Nsplit < 10 || u.lmax > 3) return TAMCMC_ERR_BAD_ARG;
-    for (int k = 0; k < 6; k++) u.g[k] = std::fabs(p[u.os + Nsplit + k]);
+    if (u.Nmax < 2 || u.Nmax != u.Nfl0 || u.Nferr < 0 || u.Nfl1 != 8 + 2 * u.Nferr || Nwidth < (cte_width ? 1 : 6) || Nsplit < 10 || u.lmax > 3)
+        return TAMCMC_ERR_BAD_ARG;
+    for (int k = 0; k < 6; k++) u.g[k] = k < (cte_width ? 1 : 6) ? std::fabs(p[u.os + Nsplit + k]) : 0.0;
     const double *fl0 = p + u.Nmax + u.lmax;
     u.Wl0.resize((size_t)u.Nmax); u.Hl0.resize((size_t)u.Nmax);
-    for (int n = 0; n < u.Nmax; n++) u.Wl0[(size_t)n] = app_width(u.g, fl0[n]);
+    for (int n = 0; n < u.Nmax; n++) u.Wl0[(size_t)n] = cte_width ? u.g[0] : app_width(u.g, fl0[n]);
     for (int n = 0; n < u.Nmax; n++)
         u.Hl0[(size_t)n] = u.do_amp ? (double)fabsl(p[n] * (1. / u.Wl0[(size_t)n] / pi)) : std::fabs(p[n]);
     const double delta0l = p[u.o1], DPl = std::fabs(p[u.o1 + 1]), alpha_g = std::fabs(p[u.o1 + 2]), q = std::fabs(p[u.o1 + 3]);
@@ -468,7 +473,9 @@ int unpack(const double *p, const int32_t *pl, double step, Unpacked &u, Prep &P
     double fit[2];
     mt::linfit_index(fl0, u.Nfl0, fit);
     const double Dnu_p = fit[0];
-    if (!(Dnu_p > 0) || u.fmin - Dnu_p < 0) return TAMCMC_ERR_BAD_ARG;  // the reference exits (models.cpp:4851-4857)
+    // the reference exits (models.cpp:4851-4857; id 27 only tests it for model_type 0, :4459, and would otherwise hand its solver a zero
+    // lower bound, i.e. an unbounded g-mode count: refused here too)
+    if (!(Dnu_p > 0) || u.fmin - Dnu_p < 0) return TAMCMC_ERR_BAD_ARG;
     P.Dnu_p = Dnu_p; P.DPl = DPl; P.alpha = alpha_g; P.q = q; P.resol = step; P.fact = 0.04;
     double fmin_s, fmax_s;
     if (u.model_type == 0) {  // solve_mm_asymptotic_O2p(Dnu_p, eps, 1, delta0l, 0, 0, ...), fmin - Dnu .. fmax + Dnu
@@ -540,12 +547,13 @@ int unpack(const double *p, const int32_t *pl, double step, Unpacked &u, Prep &P
 }  // namespace
 }  // namespace rgb
 
-// Builds the B tables of model 25 in the DEVICE staging block c->d_stage (layout StageLayout(B, stride, B*per), the one run_staged
+// Builds the B tables of model 25 / 27 in the DEVICE staging block c->d_stage (layout StageLayout(B, stride, B*per), the one run_staged
 // launches on); only the small header (counts, noise rows) goes through the host block.  One stream synchronisation (for the
 // per-vector status); no table data crosses PCIe.
-int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Nparams, const int32_t *plength, int32_t *status,
+int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *params, int64_t Nparams, const int32_t *plength, int32_t *status,
                      int *per_out, int *stride_out, int *first_err, int *tile_rot_out) {
     using namespace rgb;
+    const bool cte_width = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4_ID);
     const double *hx = c->hx.data();
     const int64_t Nx = c->Nx;
     const double step = hx[2] - hx[1];  // models.cpp:4719
@@ -568,7 +576,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Npa
         Unpacked &u = U[(size_t)b];
         RowIn &ri = R[(size_t)b];
         std::memset(&ri, 0, sizeof ri);
-        int st = unpack(p, plength, step, u, P[(size_t)b]);
+        int st = unpack(p, plength, step, cte_width, u, P[(size_t)b]);
         if (st == TAMCMC_OK && u.bias_type != 0) {
             Spline s;
             if (u.Nferr > MAXNODE || !s.set(p + u.o1 + 8, p + u.o1 + 8 + u.Nferr, u.Nferr, u.bias_type == 1 ? 1 : 2)) st = TAMCMC_ERR_BAD_ARG;
@@ -584,7 +592,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int B, const double *params, int64_t Npa
         P[(size_t)b].status = st;
         ri.status = st;
         if (st == TAMCMC_OK) {
-            ri.Nfl0 = u.Nfl0; ri.Nfl2 = u.Nfl2; ri.Nfl3 = u.Nfl3; ri.lmax = u.lmax; ri.do_amp = u.do_amp ? 1 : 0;
+            ri.Nfl0 = u.Nfl0; ri.Nfl2 = u.Nfl2; ri.Nfl3 = u.Nfl3; ri.lmax = u.lmax; ri.do_amp = u.do_amp ? 1 : 0; ri.cte_width = cte_width ? 1 : 0;
             const double *fl0 = p + u.Nmax + u.lmax;
             for (int k = 0; k < u.Nfl0; k++) { ri.fl0[k] = fl0[k]; ri.Wl0[k] = u.Wl0[(size_t)k]; ri.Hl0[k] = u.Hl0[(size_t)k]; }
             for (int k = 0; k < u.Nfl2; k++) ri.fl2[k] = std::fabs(p[u.o1 + u.Nfl1 + k]);

@@ -8,7 +8,7 @@ y = M(theta_true) * Exp(1) with M supplied by the caller (GPU path in bench.py, 
 """
 import numpy as np
 
-MODEL_CLASSIC, MODEL_LOCAL, MODEL_AJ, MODEL_RGB_V4 = 3, 11, 23, 25
+MODEL_CLASSIC, MODEL_LOCAL, MODEL_AJ, MODEL_RGB_V4, MODEL_RGB_CTE_V4 = 3, 11, 23, 25, 27
 KEPLER_4YR_RESOL = 1e6 / (4.0 * 365.0 * 86400.0)  # test_build_l_mode.cpp:107
 
 
@@ -197,11 +197,12 @@ def aj_to_classic(params, plength):
 
 
 def make_params_rgb_model(rng, nmax=6, dnu=20.0, epsilon=0.2, n_first=6, delta0l=-0.6, DPl=80.0, alpha_g=0.0, q=0.15, nferr=4,
-                          bias_type=0, model_type=0, rot_env=0.1, rot_core=0.6, inclination=55.0, trunc_c=20.0, ferr_scale=0.05):
+                          bias_type=0, model_type=0, rot_env=0.1, rot_core=0.6, inclination=55.0, trunc_c=20.0, ferr_scale=0.05, cte_width=False):
     """Parameter vector of model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (layout: SURVEY App. B; generator in the spirit of
     make_params_RGB_model, test/lorentzian_test/unit_tests/test_build_l_mode.cpp:584-767): nmax radial orders, the l=1 block
     [delta0l, DPl, alpha_g, q, -, -, Wfactor, Hfactor, fref x nferr, ferr x nferr], l=2/l=3 lists of nmax-1 modes, ten
-    rotation/asymmetry slots, the six-parameter Appourchaux width law, two Harvey profiles + white noise."""
+    rotation/asymmetry slots, the six-parameter Appourchaux width law, two Harvey profiles + white noise.
+    cte_width: the layout of model_RGB_asympt_aj_CteWidth_HarveyLike_v4 (id 27) instead: a single width parameter."""
     n = np.arange(nmax)
     fl0 = (n_first + n + epsilon) * dnu + rng.uniform(-0.01, 0.01, nmax) * dnu
     numax = fl0.mean()
@@ -214,26 +215,28 @@ def make_params_rgb_model(rng, nmax=6, dnu=20.0, epsilon=0.2, n_first=6, delta0l
     fl3 = fl0[:-1] + 0.21 * dnu
     split = np.array([rot_env, rot_core, 0.0, 0.0, 0.01, 0.0, 0.0, 0.0, 1.0, 0.0])
     width = np.array([numax, numax, 1.5, 0.15, 0.8 * numax, 2.5])          # nu_max, nu_dip, alpha, Gamma_alpha, W_dip, DeltaGamma_dip
+    if cte_width:
+        width = np.array([0.14])
     noise = np.array([30.0, 40.0, 2.0, 10.0, 8.0, 2.0, 0.4])
     cfg = np.array([trunc_c, 0.0, 0.0, float(model_type), float(bias_type), float(nferr)])
     params = np.concatenate([heights, vis, fl0, l1, fl2, fl3, split, width, noise, [inclination], cfg])
-    plength = np.array([nmax, 3, nmax, l1.size, fl2.size, fl3.size, 10, 6, 7, 1, 6], dtype=np.int32)
+    plength = np.array([nmax, 3, nmax, l1.size, fl2.size, fl3.size, 10, width.size, 7, 1, 6], dtype=np.int32)
     assert params.size == plength.sum()
     return params, plength
 
 
-def make_c5_star(seed=20240229, nx=200000, nmax=10, dnu=10.0, bias_type=1, model_type=0, nferr=6, margin=15.0):
+def make_c5_star(seed=20240229, nx=200000, nmax=10, dnu=10.0, bias_type=1, model_type=0, nferr=6, margin=15.0, cte_width=False):
     """BASELINE config C5 family: red giant, model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (id 25), prior class io_asymptotic (4).
     The l=1 mixed modes are not parameters: they follow from (delta0l, DPl, alpha_g, q) through the ARMM solver."""
     rng = np.random.default_rng(seed)
     params, plength = make_params_rgb_model(rng, nmax=nmax, dnu=dnu, n_first=6, DPl=80.0, q=0.15, nferr=nferr, bias_type=bias_type,
-                                            model_type=model_type)
+                                            model_type=model_type, cte_width=cte_width)
     o = np.cumsum([0] + list(plength))
     names = (["Height_l0"] * nmax + ["Visibility_l1", "Visibility_l2", "Visibility_l3"] + ["Frequency_l"] * nmax +
              ["delta01", "DP1", "alpha_g", "q", "sigma_H_l1", "sigma_g_l1", "Wfactor", "Hfactor"] + ["fref_bias"] * nferr + ["ferr_bias"] * nferr +
              ["Frequency_l"] * (plength[4] + plength[5]) +
              ["rot_env", "rot_core", "a2_env", "a2_core", "a3_env", "a4_env", "a5_env", "a6_env", "eta0_switch", "Lorentzian_asymetry"] +
-             ["numax", "nudip", "alpha", "Gamma_alpha", "Wdip", "DeltaGammadip"] +
+             (["Width_l0"] if cte_width else ["numax", "nudip", "alpha", "Gamma_alpha", "Wdip", "DeltaGammadip"]) +
              ["Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p", "Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p", "White_Noise_N0"] +
              ["Inclination", "Truncation_parameter", "do_amp", "sigma_limit", "model_type", "bias_type", "Nferr"])
     assert len(names) == params.size
@@ -250,6 +253,7 @@ def make_c5_star(seed=20240229, nx=200000, nmax=10, dnu=10.0, bias_type=1, model
     relax[o[9]] = 1                                         # inclination
     rules = {
         "Height_l0": (P_JEFF, lambda v: (0.1, 1.0e4)),
+        "Width_l0": (P_JEFF, lambda v: (0.01, 5.0)),
         "Frequency_l": (P_UNIFORM, lambda v: (v - 0.3 * dnu / 10.0 * 3, v + 0.3 * dnu / 10.0 * 3)),
         "delta01": (P_UNIFORM, lambda v: (v - 1.0, v + 1.0)),
         "DP1": (P_UNIFORM, lambda v: (v - 1.0, v + 1.0)),
@@ -268,4 +272,4 @@ def make_c5_star(seed=20240229, nx=200000, nmax=10, dnu=10.0, bias_type=1, model
     x = lo + (hi - lo) / nx * np.arange(nx)
     # extra_priors (io_asymptotic.cpp:422-431): [smooth switch, smooth coef, |a3/a1| limit, impose_normHnlm, model switch 3 = v4 models]
     extra = np.array([1.0, 2.0, 0.2, 0.0, 3.0, 0, 0, 0, 0, 0])
-    return Star(MODEL_RGB_V4, params, plength, x, relax, pr, sw, names, prior_class=4, extra_priors=extra)
+    return Star(MODEL_RGB_CTE_V4 if cte_width else MODEL_RGB_V4, params, plength, x, relax, pr, sw, names, prior_class=4, extra_priors=extra)

@@ -107,6 +107,8 @@ def load(fast=False):
     lib.orc_spline_eval.argtypes = [c_dp, c_dp, C.c_long, C.c_int, C.c_double]
     lib.orc_rgb_v4_modes.restype = C.c_int
     lib.orc_rgb_v4_modes.argtypes = [c_dp, c_ip, C.c_double, C.POINTER(RgbModes)]
+    lib.orc_rgb_v4_cte_modes.restype = C.c_int
+    lib.orc_rgb_v4_cte_modes.argtypes = [c_dp, c_ip, C.c_double, C.POINTER(RgbModes)]
     lib.orc_rgb_modes_free.restype = None
     lib.orc_rgb_modes_free.argtypes = [C.POINTER(RgbModes)]
     return lib
@@ -147,10 +149,10 @@ class Oracle:
         xn, yn = np.ascontiguousarray(xn, dtype=np.float64), np.ascontiguousarray(yn, dtype=np.float64)
         return np.array([self.lib.orc_spline_eval(_dp(xn), _dp(yn), xn.size, kind, float(v)) for v in np.atleast_1d(x)])
 
-    def rgb_modes(self, params, plength, step):
+    def rgb_modes(self, params, plength, step, cte_width=False):
         p, pl = np.ascontiguousarray(params, dtype=np.float64), np.ascontiguousarray(plength, dtype=np.int32)
         m = self.lib.RgbModes()
-        rc = self.lib.orc_rgb_v4_modes(_dp(p), _ip(pl), float(step), C.byref(m))
+        rc = (self.lib.orc_rgb_v4_cte_modes if cte_width else self.lib.orc_rgb_v4_modes)(_dp(p), _ip(pl), float(step), C.byref(m))
         if rc != 0:
             return rc, None
         take = lambda q, n: np.array([q[i] for i in range(n)])

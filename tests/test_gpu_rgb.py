@@ -7,13 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bias_type,model_type", [(0, 0), (1, 0), (2, 1), (0, 1)])
-def test_rgb_model_rows_and_logl_match_the_oracle(pkg, oracle, synth, bias_type, model_type):
+@pytest.mark.parametrize("bias_type,model_type,cte", [(0, 0, False), (1, 0, False), (2, 1, False), (0, 1, False), (1, 0, True), (0, 1, True)])
+def test_rgb_model_rows_and_logl_match_the_oracle(pkg, oracle, synth, bias_type, model_type, cte):
     rng = np.random.default_rng(5)
-    params, pl = synth.make_params_rgb_model(rng, bias_type=bias_type, model_type=model_type)
+    params, pl = synth.make_params_rgb_model(rng, bias_type=bias_type, model_type=model_type, cte_width=cte)
+    model_id = synth.MODEL_RGB_CTE_V4 if cte else synth.MODEL_RGB_V4     # 27: constant-width variant (models.cpp:4334)
     step = 0.05
     x = 110.0 + step * np.arange(3400)
-    st, m0 = oracle.call_model(synth.MODEL_RGB_V4, params, pl, x)
+    st, m0 = oracle.call_model(model_id, params, pl, x)
     assert st == 0
     y = m0 * np.random.default_rng(2).exponential(1.0, m0.size)
     B = 5
@@ -23,12 +24,14 @@ def test_rgb_model_rows_and_logl_match_the_oracle(pkg, oracle, synth, bias_type,
     P[1:, o[3] + 1] *= 1 + 0.002 * rng.standard_normal(B - 1)                        # period spacing: moves every mixed mode
     P[1:, o[3] + 3] *= 1 + 0.05 * rng.standard_normal(B - 1)                         # coupling
     T = 1.4 ** np.arange(B)
-    ref, m_o, st_o = oracle.loglike_batch(synth.MODEL_RGB_V4, P, pl, x, y, 1.0, T, want_model=True)
+    if cte:
+        P[1:, o[7]] *= 1 + 0.1 * rng.standard_normal(B - 1)                          # the one width
+    ref, m_o, st_o = oracle.loglike_batch(model_id, P, pl, x, y, 1.0, T, want_model=True)
     assert (st_o == 0).all()
     for prec, tol_m, tol_l in ((pkg.PRECISION_STRICT, 1e-7, 1e-8), (pkg.PRECISION_FAST, 1e-7, 1e-8)):
         ctx = pkg.HipContext(0, precision=prec)
         ctx.set_spectrum(x, y)
-        got, m_d, st_d = ctx.loglike_params_batch(pkg.MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4, P, pl, T, want_model=True)
+        got, m_d, st_d = ctx.loglike_params_batch(model_id, P, pl, T, want_model=True)
         assert (st_d == 0).all()
         # same mixed modes (a missing or extra mode would change the row by O(1) around it); frequencies agree to ~1e-10 muHz
         # (device tan/atan in double vs the reference's long double), i.e. ~1e-8 relative on a 0.05 muHz-wide profile
@@ -57,11 +60,12 @@ def test_rgb_bad_vectors_are_reported_not_guessed(pkg, oracle, synth):
     ctx.close()
 
 
-def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth):
+@pytest.mark.parametrize("cte", [False, True])
+def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth, cte):
     """Red-giant star end to end: priors (io_asymptotic) on the host, ONE batched device call per iteration whose tables come from
     the device pre-step, adaptive MH + parallel tempering (host-driven engine; the device-resident engine does not carry the
     pre-step yet and must refuse the model)."""
-    star = synth.make_c5_star(nx=6000, nmax=6, nferr=4)
+    star = synth.make_c5_star(nx=6000, nmax=6, nferr=4, cte_width=cte)
     st, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
     assert st == 0
     star.set_spectrum_from_model(m0, 4)

@@ -127,3 +127,29 @@ def test_rgb_model_is_the_sum_of_its_modes(oracle, synth, bias_type, model_type)
         p2[o[11] - 2] = 1.0                       # cubic spline through all-zero nodes = no bias
         st2, m2 = oracle.call_model(synth.MODEL_RGB_V4, p2, pl, x)
         assert st2 == 0 and np.allclose(m2, m, rtol=1e-13)
+
+
+@pytest.mark.parametrize("bias_type,model_type", [(0, 0), (1, 1)])
+def test_constant_width_variant_differs_only_by_its_width_law(oracle, synth, bias_type, model_type):
+    """model_RGB_asympt_aj_CteWidth_HarveyLike_v4 (id 27, models.cpp:4334-4682): one width for every l=0/2/3 mode (:4407, :4561, :4582);
+    the mixed-mode frequencies, zeta and splittings are those of id 25 on the same remaining parameters."""
+    p27, pl27 = synth.make_params_rgb_model(np.random.default_rng(5), bias_type=bias_type, model_type=model_type, cte_width=True)
+    p25, pl25 = synth.make_params_rgb_model(np.random.default_rng(5), bias_type=bias_type, model_type=model_type)
+    step = 0.05
+    x = 110.0 + step * np.arange(3400)
+    rc27, m27 = oracle.rgb_modes(p27, pl27, step, cte_width=True)
+    rc25, m25 = oracle.rgb_modes(p25, pl25, step)
+    assert rc27 == 0 and rc25 == 0
+    assert np.array_equal(m27["fl1"], m25["fl1"]) and np.array_equal(m27["ksi"], m25["ksi"]) and np.array_equal(m27["a1_l1"], m25["a1_l1"])
+    assert np.all(m27["Wl0"] == 0.14)
+    hr = np.sqrt(1 - 0.9 * m27["ksi"])
+    assert np.allclose(m27["Wl1"], 0.14 * (1 - 0.9 * m27["ksi"]) / np.sqrt(hr), rtol=1e-13)     # gamma_l_fct2 on a flat l=0 width
+    st, row = oracle.call_model(synth.MODEL_RGB_CTE_V4, p27, pl27, x)
+    assert st == 0 and np.all(np.isfinite(row)) and np.all(row > 0)
+    # an Appourchaux law that is flat over the band (alpha = 0, no dip) gives the same spectrum as the constant-width model
+    o = np.cumsum([0] + list(pl25))
+    p25[o[7]:o[8]] = [130.0, 130.0, 0.0, 0.14, 260.0, 1.0]
+    st, row25 = oracle.call_model(synth.MODEL_RGB_V4, p25, pl25, x)
+    assert st == 0 and np.allclose(row25, row, rtol=1e-12)
+    # the width block is one parameter long: the six-parameter layout is refused, as is a shorter one for id 25
+    assert oracle.call_model(synth.MODEL_RGB_V4, p27, pl27, x)[0] != 0
