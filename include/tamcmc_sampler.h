@@ -104,6 +104,16 @@ int tamcmc_outputs_read_params(const char *root, int32_t chain, double *samples,
 int tamcmc_params_summary(const double *samples, int64_t n, int32_t Nvars, int64_t row_stride, double *mean, double *median,
                           double *stddev);
 
+/* Evidence diagnostic of the tempered ladder (Diagnostics::evidence_calc, diagnostics.cpp:980-1019; quad_interpol, interpol.cpp:46-101):
+ * beta = 1/Tcoefs, L_beta[m] = mean recorded log-likelihood of chain m, both resampled to interp_factor*Nchains points, evidence =
+ * average of the resampled L_beta.  logL[i*row_stride + m*col_stride]: for tamcmc_sampler_run's stats block pass row_stride =
+ * 3*Nchains, col_stride = 3.  beta_interp / L_beta_interp ([interp_factor*Nchains]) may be NULL. */
+int tamcmc_evidence_calc(const double *Tcoefs, int32_t Nchains, const double *logL, int64_t n, int64_t row_stride, int64_t col_stride,
+                         int32_t interp_factor, double *beta, double *L_beta, double *beta_interp, double *L_beta_interp, double *evidence);
+/* appends one line (sample count, L_beta, evidence) to the text file the reference's diagnostics keep (diagnostics.cpp:1021-1066) */
+int tamcmc_outputs_write_evidence(const char *file, int64_t n_samples, int32_t Nchains, const double *beta, const double *L_beta,
+                                  int32_t interp_factor, double evidence, int32_t first);
+
 /* Host log-prior of one parameter vector = Model_def::call_prior (model_def.cpp:421-464) for the model classes
  * io_MS_Global (2) and io_local (3): long double arithmetic, the reference's term order.  *status (may be NULL) receives
  * TAMCMC_ERR_BAD_MODEL for prior ids / model families this build does not carry. */

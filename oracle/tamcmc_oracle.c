@@ -861,3 +861,44 @@ double orc_call_prior(int prior_class, const double *params, const int *pl, cons
     if (prior_class == 4) return (double)orc_priors_asymptotic(params, pl, pr, sw, extra);
     return NAN;
 }
+
+/* ---- evidence diagnostic: interpol.cpp:46-101 (quad_interpol, interp1, parabola, interp2), diagnostics.cpp:980-1019 ---- */
+static long double orc_interp1(long double x, const double *a, long n) { /* interpol.cpp:64-72 */
+    if (x <= 0) return a[0];
+    if (x >= n - 1) return a[n - 1];
+    int j = (int)x;
+    return a[j] + (x - j) * (a[j + 1] - a[j]);
+}
+static long double orc_parabola(long double x, long double f_1, long double f0, long double f1) { /* :86-92 */
+    if (x <= -1) return f_1;
+    if (x >= 1) return f1;
+    long double l = f0 - x * (f_1 - f0);
+    long double r = f0 + x * (f1 - f0);
+    return (l + r + x * (r - l)) / 2;
+}
+static long double orc_interp2(long double x, const double *a, long n) { /* :95-101 */
+    if (x <= .5 || x >= n - 1.5) return orc_interp1(x, a, n);
+    int j = (int)(x + .5);
+    long double t = 2 * (x - j);
+    return orc_parabola(t, (a[j - 1] + a[j]) / 2, a[j], (a[j] + a[j + 1]) / 2);
+}
+void orc_quad_interpol(const double *a, long n, long m, double *b) { /* :46-59 */
+    long double step = (double)(n - 1) / (m - 1);
+    for (long j = 0; j < m; j++) b[j] = (double)orc_interp2(j * step, a, n);
+}
+/* Likelihoods: [rows x Nchains] row-major (first Nchains columns of the stat_criteria table, diagnostics.cpp:224) */
+double orc_evidence_calc(const double *Tcoefs, long Nchains, const double *Likelihoods, long rows, int interpol_factor, double *beta,
+                         double *L_beta, double *beta_interp, double *L_beta_interp) {
+    const long Npts = interpol_factor * Nchains;
+    for (long i = 0; i < Nchains; i++) {
+        beta[i] = 1. / Tcoefs[i];
+        double s = 0;
+        for (long r = 0; r < rows; r++) s += Likelihoods[r * Nchains + i];
+        L_beta[i] = s / rows;
+    }
+    orc_quad_interpol(beta, Nchains, Npts, beta_interp);
+    orc_quad_interpol(L_beta, Nchains, Npts, L_beta_interp);
+    double tot = 0;
+    for (long j = 0; j < Npts; j++) tot += L_beta_interp[j];
+    return tot / Npts;
+}

@@ -138,6 +138,11 @@ int orc_fd_gradient(int model_id, const double *params, long Nparams, const int 
                     const double *y, long Nx, double likelihood_params, double Tcoef, double *logL0,
                     double *grad /*Nvars*/);
 
+/* ---- evidence diagnostic (interpol.cpp:46-101; diagnostics.cpp:980-1019) ---- */
+void orc_quad_interpol(const double *a, long n, long m, double *b);
+double orc_evidence_calc(const double *Tcoefs, long Nchains, const double *Likelihoods /*[rows x Nchains]*/, long rows, int interpol_factor,
+                         double *beta, double *L_beta, double *beta_interp, double *L_beta_interp);
+
 /* ---- priors (stats_dictionary.cpp; priors_calc.cpp:725-870) ---- */
 long double orc_logP_uniform(double b_min, double b_max, double x);                /* stats_dictionary.cpp:38-52 */
 long double orc_logP_gaussian(double mean, double sigma, double x);                /* :98-105 */

@@ -3,7 +3,8 @@
 //   <root>params.hdr + <root>params_chain-<m>.bin   Outputs::write_bin_params          outputs.cpp:1231-1333
 //   <root>stat_criteria.hdr + .bin                    Outputs::write_bin_stat_criteria  outputs.cpp:1472-1550
 // and the summary statistics the reference's tools print per variable (tools/quick_samples_stats.cpp:4-35,
-// used by tools/bin2txt_params.cpp:165-168): mean, median, population standard deviation.
+// used by tools/bin2txt_params.cpp:165-168): mean, median, population standard deviation;
+//   <file>.txt evidence diagnostic                     Diagnostics::evidence_calc / write_evidence  diagnostics.cpp:980-1066
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -135,6 +136,80 @@ int tamcmc_params_summary(const double *samples, int64_t n, int32_t Nvars, int64
         stddev[v] = std::sqrt(q / (double)n);
     }
     return TAMCMC_OK;
+}
+
+// ---- evidence diagnostic from the tempered ladder (Diagnostics::evidence_calc, diagnostics.cpp:980-1019) ----
+// beta_m = 1/T_m, L_beta_m = mean over the samples of chain m's recorded log-likelihood; both ladders are resampled to
+// interp_factor*Nchains points on the INDEX axis (quad_interpol, interpol.cpp:46-59: half-sample parabolas, linear in the first and
+// last half interval) and the figure the reference calls the evidence is the plain average of the resampled L_beta.
+namespace {
+long double resample_at(const double *a, int n, long double x) {  // interp2 / interp1 / parabola, interpol.cpp:64-101
+    if (x <= .5L || x >= (long double)n - 1.5L) {
+        if (x <= 0) return a[0];
+        if (x >= n - 1) return a[n - 1];
+        const int j = (int)x;
+        return a[j] + (x - j) * (a[j + 1] - a[j]);
+    }
+    const int j = (int)(x + .5L);
+    const long double t = 2 * (x - j);
+    const long double fm = ((long double)a[j - 1] + a[j]) / 2, f0 = a[j], fp = ((long double)a[j] + a[j + 1]) / 2;
+    if (t <= -1) return fm;
+    if (t >= 1) return fp;
+    const long double l = f0 - t * (fm - f0), r = f0 + t * (fp - f0);
+    return (l + r + t * (r - l)) / 2;
+}
+void resample(const double *a, int n, int m, double *out) {
+    const long double step = (long double)((double)(n - 1) / (m - 1));
+    for (int j = 0; j < m; j++) out[j] = (double)resample_at(a, n, j * step);
+}
+}  // namespace
+
+// logL[i*row_stride + m*col_stride] = recorded log-likelihood of chain m at sample i (tamcmc_sampler_run's stats block:
+// row_stride 3*Nchains, col_stride 3; the reference's stat_criteria rows: 3*Nchains, 1).  beta, L_beta: [Nchains];
+// beta_interp, L_beta_interp: [interp_factor*Nchains] (either may be NULL).
+int tamcmc_evidence_calc(const double *Tcoefs, int32_t Nchains, const double *logL, int64_t n, int64_t row_stride, int64_t col_stride,
+                         int32_t interp_factor, double *beta, double *L_beta, double *beta_interp, double *L_beta_interp, double *evidence) {
+    if (!Tcoefs || !logL || !beta || !L_beta || !evidence || Nchains < 1 || n < 1 || interp_factor < 1 || row_stride < 1 || col_stride < 1)
+        return TAMCMC_ERR_BAD_ARG;
+    const int npts = interp_factor * Nchains;
+    if (npts < 2) return TAMCMC_ERR_BAD_ARG;  // the resampling step divides by npts - 1
+    for (int32_t m = 0; m < Nchains; m++) {
+        beta[m] = 1. / Tcoefs[m];
+        double s = 0;
+        for (int64_t i = 0; i < n; i++) s += logL[(size_t)i * (size_t)row_stride + (size_t)m * (size_t)col_stride];
+        L_beta[m] = s / (double)n;
+    }
+    std::vector<double> bi((size_t)npts), li((size_t)npts);
+    resample(beta, Nchains, npts, bi.data());
+    resample(L_beta, Nchains, npts, li.data());
+    double tot = 0;
+    for (int j = 0; j < npts; j++) tot += li[(size_t)j];
+    *evidence = tot / npts;
+    if (beta_interp) std::copy(bi.begin(), bi.end(), beta_interp);
+    if (L_beta_interp) std::copy(li.begin(), li.end(), L_beta_interp);
+    return TAMCMC_OK;
+}
+
+// One line of <file> per call: sample count, L_beta[0:Nchains], evidence; header on the first call (write_evidence, diagnostics.cpp:1021-1066)
+int tamcmc_outputs_write_evidence(const char *file, int64_t n_samples, int32_t Nchains, const double *beta, const double *L_beta,
+                                  int32_t interp_factor, double evidence, int32_t first) {
+    if (!file || !beta || !L_beta || Nchains < 1) return TAMCMC_ERR_BAD_ARG;
+    FILE *f = std::fopen(file, first ? "w" : "a");
+    if (!f) return TAMCMC_ERR_BAD_ARG;
+    if (first) {
+        std::fprintf(f, "# This is an output file for the evidence. Evidence is calculated after a quadratic interpolation of L_beta. \n");
+        std::fprintf(f, "# This file contains values for the L_beta[0:Nchains-1], the evidence calculated at each time the buffer was written \n");
+        std::fprintf(f, "# col(1): Number of samples used to compute the evidence \n");
+        std::fprintf(f, "# col(2:2+Nchains): averaged probability <P(D|M,I)> over the samples of each chain \n");
+        std::fprintf(f, "# col(2+Nchains+1): Evidence P(M|D, I) computed by (1) interpolation and (2) averaging \n");
+        std::fprintf(f, "! beta=");
+        for (int32_t m = 0; m < Nchains; m++) std::fprintf(f, "%s%.6g", m ? " " : "", beta[m]);
+        std::fprintf(f, "\n! interpolation_factor=%d\n", (int)interp_factor);
+    }
+    std::fprintf(f, "%lld ", (long long)n_samples);
+    for (int32_t m = 0; m < Nchains; m++) std::fprintf(f, "%s%20.10g", m ? " " : "", L_beta[m]);
+    std::fprintf(f, " %20.10g\n", evidence);
+    return std::fclose(f) == 0 ? TAMCMC_OK : TAMCMC_ERR_BAD_ARG;
 }
 
 }  // extern "C"

@@ -38,6 +38,8 @@ EXTRA_ABI += [
     ("tamcmc_outputs_write_stat_criteria", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32]),
     ("tamcmc_outputs_read_params", C.c_int, [C.c_char_p, C.c_int32, _dp, C.c_int64, _i64p, _ip, _ip]),
     ("tamcmc_params_summary", C.c_int, [_dp, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, _dp]),
+    ("tamcmc_evidence_calc", C.c_int, [_dp, C.c_int32, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp, _dp, _dp, _dp, C.POINTER(C.c_double)]),
+    ("tamcmc_outputs_write_evidence", C.c_int, [C.c_char_p, C.c_int64, C.c_int32, _dp, _dp, C.c_int32, C.c_double, C.c_int32]),
     ("tamcmc_log_prior", C.c_double, [C.c_int, _dp, C.c_int64, _ip, _dp, _ip, _dp, C.c_int32, _ip]),
 ]
 
@@ -225,3 +227,24 @@ def params_summary(samples2d):
     if st != OK:
         raise TamcmcError(st, "tamcmc_params_summary")
     return mean, med, sd
+
+
+def evidence(Tcoefs, stats, interp_factor=1000, out_file=None, first=True):
+    """Evidence diagnostic of the tempered ladder (Diagnostics::evidence_calc, diagnostics.cpp:980-1019) from the [n x Nchains x 3]
+    statistics block of Sampler.run; optionally appends the reference's text line (write_evidence, :1021-1066).
+    Returns (evidence, beta, L_beta, beta_interp, L_beta_interp)."""
+    L = _rebind()
+    T = _f64(Tcoefs)
+    st3 = _f64(stats)
+    n, nc = st3.shape[0], st3.shape[1]
+    beta, Lb = np.zeros(nc), np.zeros(nc)
+    bi, Li = np.zeros(nc * interp_factor), np.zeros(nc * interp_factor)
+    ev = C.c_double(0)
+    rc = L.tamcmc_evidence_calc(_p(T), nc, _p(st3), n, 3 * nc, 3, int(interp_factor), _p(beta), _p(Lb), _p(bi), _p(Li), C.byref(ev))
+    if rc != OK:
+        raise TamcmcError(rc, "tamcmc_evidence_calc")
+    if out_file is not None:
+        rc = L.tamcmc_outputs_write_evidence(str(out_file).encode(), n, nc, _p(beta), _p(Lb), int(interp_factor), ev.value, int(bool(first)))
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_outputs_write_evidence")
+    return ev.value, beta, Lb, bi, Li

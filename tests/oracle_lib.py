@@ -107,6 +107,10 @@ def load(fast=False):
     lib.orc_spline_eval.argtypes = [c_dp, c_dp, C.c_long, C.c_int, C.c_double]
     lib.orc_rgb_v4_modes.restype = C.c_int
     lib.orc_rgb_v4_modes.argtypes = [c_dp, c_ip, C.c_double, C.POINTER(RgbModes)]
+    lib.orc_quad_interpol.restype = None
+    lib.orc_quad_interpol.argtypes = [c_dp, C.c_long, C.c_long, c_dp]
+    lib.orc_evidence_calc.restype = C.c_double
+    lib.orc_evidence_calc.argtypes = [c_dp, C.c_long, c_dp, C.c_long, C.c_int, c_dp, c_dp, c_dp, c_dp]
     lib.orc_rgb_v4_cte_modes.restype = C.c_int
     lib.orc_rgb_v4_cte_modes.argtypes = [c_dp, c_ip, C.c_double, C.POINTER(RgbModes)]
     lib.orc_rgb_modes_free.restype = None
@@ -148,6 +152,20 @@ class Oracle:
     def spline_eval(self, xn, yn, kind, x):
         xn, yn = np.ascontiguousarray(xn, dtype=np.float64), np.ascontiguousarray(yn, dtype=np.float64)
         return np.array([self.lib.orc_spline_eval(_dp(xn), _dp(yn), xn.size, kind, float(v)) for v in np.atleast_1d(x)])
+
+    def quad_interpol(self, a, m):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.zeros(m)
+        self.lib.orc_quad_interpol(_dp(a), a.size, m, _dp(b))
+        return b
+
+    def evidence(self, Tcoefs, logL, interp_factor):
+        T = np.ascontiguousarray(Tcoefs, dtype=np.float64)
+        Lk = np.ascontiguousarray(logL, dtype=np.float64)
+        n = T.size
+        beta, Lb, bi, Li = np.zeros(n), np.zeros(n), np.zeros(n * interp_factor), np.zeros(n * interp_factor)
+        ev = self.lib.orc_evidence_calc(_dp(T), n, _dp(Lk), Lk.shape[0], interp_factor, _dp(beta), _dp(Lb), _dp(bi), _dp(Li))
+        return ev, beta, Lb, bi, Li
 
     def rgb_modes(self, params, plength, step, cte_width=False):
         p, pl = np.ascontiguousarray(params, dtype=np.float64), np.ascontiguousarray(plength, dtype=np.int32)

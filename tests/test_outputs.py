@@ -55,3 +55,36 @@ def test_restore_files_round_trip(pkg, tmp_path):
     assert np.array_equal(v2, vars_) and np.array_equal(s2, sig) and np.array_equal(m2, mus) and np.array_equal(c2, cov)
     assert L.tamcmc_outputs_read_restore(str(tmp_path / "absent_").encode(), S._p(a, S._ip), S._p(b, S._ip), S._p(c, S._i64p), None, None,
                                          None, None) != 0
+
+
+def test_evidence_diagnostic_matches_the_oracle_and_known_answers(pkg, oracle, tmp_path):
+    """Diagnostics::evidence_calc (diagnostics.cpp:980-1019) on top of quad_interpol (interpol.cpp:46-101): known answers, then the
+    host library against the oracle's restatement on random ladders."""
+    from tamcmc_c_amd import sampler as S
+    # quad_interpol: resampling to the same length returns the nodes; a straight line stays a straight line; the half-sample
+    # parabolas reproduce the node values and are linear in the first and last half interval
+    a = np.array([3.0, 1.0, 4.0, 1.0, 5.0, 9.0])
+    assert np.array_equal(oracle.quad_interpol(a, a.size), a)
+    lin = 2.0 + 0.5 * np.arange(7)
+    assert np.allclose(oracle.quad_interpol(lin, 61), np.linspace(lin[0], lin[-1], 61), rtol=1e-15)
+    fine = oracle.quad_interpol(a, 51)                       # index step 0.1
+    assert np.allclose(fine[::10], a, rtol=1e-15) and np.allclose(fine[:6], a[0] + 0.1 * np.arange(6) * (a[1] - a[0]))
+    assert np.isclose(fine[15], (0.5 * (a[1] + a[2]) + 0.5 * (a[1] + a[2])) / 2)   # x = 1.5: the parabola's end value, the mid-point mean
+    rng = np.random.default_rng(11)
+    for nc, n, k in ((4, 300, 7), (10, 57, 1000), (2, 5, 3)):
+        T = 1.7 ** np.arange(nc)
+        stats = rng.standard_normal((n, nc, 3)) * 5 - 1000.0 / T[None, :, None]
+        ev, beta, Lb, bi, Li = S.evidence(T, stats, k, out_file=tmp_path / "ev.txt", first=True)
+        ev_o, beta_o, Lb_o, bi_o, Li_o = oracle.evidence(T, stats[:, :, 0], k)
+        assert np.array_equal(beta, 1.0 / T) and np.array_equal(beta, beta_o)
+        assert np.allclose(Lb, stats[:, :, 0].mean(0), rtol=1e-14) and np.allclose(Lb, Lb_o, rtol=1e-15)
+        assert np.allclose(bi, bi_o, rtol=1e-15) and np.allclose(Li, Li_o, rtol=1e-14) and np.isclose(ev, ev_o, rtol=1e-14)
+        assert Li.min() >= Lb.min() - 1e-9 and Li.max() <= Lb.max() + 1e-9      # monotone ladder: the resampling does not overshoot
+        S.evidence(T, stats, k, out_file=tmp_path / "ev.txt", first=False)
+        lines = open(tmp_path / "ev.txt").read().splitlines()
+        body = [ln for ln in lines if not ln.startswith(("#", "!"))]
+        assert len(body) == 2 and lines[5].startswith("! beta=") and lines[6] == f"! interpolation_factor={k}"
+        cols = np.array(body[1].split(), dtype=float)
+        assert cols[0] == n and np.allclose(cols[1:1 + nc], Lb, rtol=1e-9) and np.isclose(cols[-1], ev, rtol=1e-9)
+    with np.testing.assert_raises(Exception):
+        S.evidence(np.array([1.0]), np.zeros((3, 1, 3)), 1)        # one resampled point: the reference divides by zero
