@@ -19,6 +19,10 @@ import time
 
 import numpy as np
 
+# the 'packed' leg runs several stars' streams side by side: give every live stream its own hardware queue (ROCclr default: 4; two
+# streams that share a queue serialise).  Must be set before the HIP runtime starts; the one-star headline does not depend on it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
@@ -44,6 +48,9 @@ def parse():
     ap.add_argument("--mala-steps", type=int, default=30, help="extra MALA-FD measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--packed-stars", type=int, default=4,
+                    help="extra leg at N=1: this many independent C3 stars co-resident on the GPU (0 = skip); reported under 'packed', "
+                         "never as 'value' (the headline stays one star per GPU, BASELINE configs[2])")
     ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
     return ap.parse_args()
 
@@ -150,6 +157,37 @@ def main():
                             "evals_per_step": mk_e / a.mala_steps, "kernel_us_per_launch": mk_ms / max(mk_l, 1) * 1e3,
                             "alg_GBps": 16.0 * a.nx * mk_e / max(mk_ms * 1e-3, 1e-12) / 1e9}
         ms.close()
+
+    if a.packed_stars > 1 and a.sampler == "mh" and a.engine == "device" and world == 1:
+        # Several independent stars on ONE GPU (one context + one device-resident sampler + one host thread per star,
+        # tamcmc_sampler_run_packed): a single star's iteration is two short dependent kernels, co-resident stars fill the idle SIMDs.
+        from tamcmc_c_amd import sampler as smod
+        pool = []
+        for k in range(a.packed_stars):
+            sk = synth.make_c3_star(seed=20240229 + 100 + k, nx=a.nx, step=2000.0 / a.nx)
+            ck = pkg.HipContext(device_index, precision=pkg.PRECISION_STRICT)
+            ck.set_spectrum(sk.x, np.ones_like(sk.x))
+            _, mk, _ = ck.loglike_params_batch(sk.model_id, sk.params, sk.plength, want_model=True)
+            yk = sk.set_spectrum_from_model(mk[0], seed=20240301 + 100 + k)
+            ck.set_option(pkg.OPT_PRECISION, prec)
+            ck.set_spectrum(sk.x, yk)
+            pool.append((ck, pkg.Sampler(ck, sk, nchains=a.chains, lambda_temp=lam, seed=107 + k, engine="device", chain_groups=1,
+                                         Nt_learn=(max(a.warmup // 2, 1), max(a.warmup, 2)), periods_learn=(1,), dN_mixing=a.dn_mixing)))
+        ps = [q[1] for q in pool]
+        smod.run_packed(ps, a.warmup, record=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        smod.run_packed(ps, a.steps, record=False)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        rate = a.packed_stars * a.steps / e1
+        extra["packed"] = {"stars_per_gpu": a.packed_stars, "samples_per_s": rate, "us_per_star_iteration": 1e6 * e1 / (a.steps * a.packed_stars),
+                           "alg_GBps": rate * a.chains * 16.0 * a.nx / 1e9, "frac_of_hbm_peak": rate * a.chains * 16.0 * a.nx / 1e9 / HBM_PEAK_GBS,
+                           "note": "aggregate over the co-resident stars (each a full 20-chain C3 fit, one stream group per star); "
+                                   "every star's samples are bit-identical to its solo run (tests/test_gpu_sampler.py)"}
+        for ck, sk_ in pool:
+            sk_.close()
+            ck.close()
 
     shapes = []
     if world == 1 and a.sampler == "mh":

@@ -57,6 +57,7 @@ struct DevSamplerInit {
     uint64_t seed;
     long dN_mixing;
     double c0, epsilon1, epsi2, A1, target_acceptance;
+    int chain_groups = 0;  // 0 = default (TAMCMC_CHAIN_GROUPS, else 2 from 8 chains on)
 };
 
 class DevSampler {

@@ -746,7 +746,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     {
         if (const char *ep = getenv("TAMCMC_PRE_LZ")) I.pre_lz = atoi(ep) != 0;
         const char *eg = getenv("TAMCMC_CHAIN_GROUPS");
-        int G = eg ? atoi(eg) : (in.C >= 8 ? 2 : 1);
+        int G = in.chain_groups > 0 ? in.chain_groups : eg ? atoi(eg) : (in.C >= 8 ? 2 : 1);
         if (G < 1) G = 1;
         if (G > 4) G = 4;
         if (G > in.C) G = in.C;

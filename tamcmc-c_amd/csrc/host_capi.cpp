@@ -4,6 +4,7 @@
 #include <memory>
 #include <vector>
 #include <string>
+#include <thread>
 
 #include "../../include/tamcmc_sampler.h"
 #include "dev_sampler.h"
@@ -17,6 +18,7 @@ struct tamcmc_sampler {
     std::unique_ptr<Model_def> cur, prop;
     std::unique_ptr<DevSampler> dev;  // engine 1: the iteration runs on the GPU, the host objects mirror its state
     long accepted0 = 0;
+    tamcmc_hip_ctx *ctx = nullptr;  // borrowed
     int sync_from_device(bool proposal_too);
 };
 
@@ -93,6 +95,7 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
     g.MALA.seed = c->seed;
     g.MALA.fd_step_rel = c->fd_step_rel > 0 ? c->fd_step_rel : 1e-7;
     s->mala = std::make_unique<MALA>(&g);
+    s->ctx = ctx;
     s->cur = std::make_unique<Model_def>(&g, s->mala->Tcoefs, false, ctx);
     if (s->cur->last_status != TAMCMC_OK) return s->cur->last_status;
     s->prop = std::make_unique<Model_def>(*s->cur);
@@ -105,7 +108,7 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
         di.likelihood_params = c->likelihood_params;
         di.plength = in.plength.data(); di.index_to_relax = idx.data(); di.priors_switch = in.priors_names_switch.data();
         di.priors = in.priors.a.data(); di.extra_priors = in.extra_priors.data(); di.Tcoefs = s->mala->Tcoefs.data();
-        di.seed = c->seed; di.dN_mixing = (long)c->dN_mixing;
+        di.seed = c->seed; di.dN_mixing = (long)c->dN_mixing; di.chain_groups = c->chain_groups;
         di.c0 = c->c0; di.epsilon1 = c->epsilon1; di.epsi2 = c->epsilon2; di.A1 = c->A1; di.target_acceptance = c->target_acceptance;
         int rc = s->dev->init(ctx, di);
         if (rc) return rc;
@@ -152,6 +155,25 @@ int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, doubl
                 r[2] = s->cur->logPosterior[(size_t)m];
             }
     }
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_run_packed(tamcmc_sampler *const *s, int32_t S, int64_t n_iter, double *const *samples, double *const *stats) {
+    if (!s || S < 1 || n_iter < 0) return TAMCMC_ERR_BAD_ARG;
+    for (int32_t k = 0; k < S; k++) {
+        if (!s[k]) return TAMCMC_ERR_BAD_ARG;
+        for (int32_t j = 0; j < k; j++)
+            if (s[j] == s[k] || s[j]->ctx == s[k]->ctx) return TAMCMC_ERR_BAD_ARG;  // a context (its stream, its staging blocks) serves ONE sampler at a time
+    }
+    std::vector<int> rc((size_t)S, TAMCMC_OK);
+    std::vector<std::thread> th;
+    th.reserve((size_t)S);
+    for (int32_t k = 1; k < S; k++)
+        th.emplace_back([&, k] { rc[(size_t)k] = tamcmc_sampler_run(s[k], n_iter, samples ? samples[k] : nullptr, stats ? stats[k] : nullptr); });
+    rc[0] = tamcmc_sampler_run(s[0], n_iter, samples ? samples[0] : nullptr, stats ? stats[0] : nullptr);
+    for (auto &t : th) t.join();
+    for (int32_t k = 0; k < S; k++)
+        if (rc[(size_t)k]) return rc[(size_t)k];
     return TAMCMC_OK;
 }
 

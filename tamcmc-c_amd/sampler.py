@@ -17,7 +17,7 @@ class SamplerConfig(C.Structure):
                 ("epsilon1", C.c_double), ("epsilon2", C.c_double), ("A1", C.c_double), ("delta", C.c_double),
                 ("delta_x", C.c_double), ("Nt_learn", _i64p), ("periods_learn", _i64p), ("n_Nt_learn", C.c_int32),
                 ("engine", C.c_int32), ("dN_mixing", C.c_int64), ("init_errors", _dp), ("seed", C.c_uint64),
-                ("fd_step_rel", C.c_double)]
+                ("fd_step_rel", C.c_double), ("chain_groups", C.c_int32)]
 
 
 EXTRA_ABI += [
@@ -25,6 +25,7 @@ EXTRA_ABI += [
     ("tamcmc_sampler_destroy", None, [_vp]),
     ("tamcmc_sampler_nvars", C.c_int64, [_vp]),
     ("tamcmc_sampler_run", C.c_int, [_vp, C.c_int64, _dp, _dp]),
+    ("tamcmc_sampler_run_packed", C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int64, C.POINTER(_dp), C.POINTER(_dp)]),
     ("tamcmc_sampler_get_state", C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _i64p]),
     ("tamcmc_sampler_get_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp]),
     ("tamcmc_sampler_set_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_double]),
@@ -61,7 +62,7 @@ class Sampler:
     def __init__(self, ctx: HipContext, star, nchains=5, lambda_temp=3.5, use_drift=0, seed=20240229, p=1.0,
                  target_acceptance=0.234, c0=10.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, delta=0.0, delta_x=1e-10,
                  Nt_learn=(1000, 1500, 100000), periods_learn=(1, 1), dN_mixing=1, init_errors=None, fd_step_rel=1e-7,
-                 engine="host"):
+                 engine="host", chain_groups=0):
         self._L = _rebind()
         self.ctx = ctx
         self.nchains = int(nchains)
@@ -90,6 +91,7 @@ class Sampler:
         cfg.Nt_learn, cfg.periods_learn, cfg.n_Nt_learn = _p(keep["Nt"], _i64p), _p(keep["per"], _i64p), keep["Nt"].size
         cfg.dN_mixing, cfg.init_errors, cfg.seed, cfg.fd_step_rel = int(dN_mixing), _p(keep["err"]), int(seed), fd_step_rel
         cfg.engine = {"host": 0, "device": 1}[engine]
+        cfg.chain_groups = int(chain_groups)
         h = _vp()
         st = self._L.tamcmc_sampler_create(C.byref(h), ctx._h, C.byref(cfg))
         if st != OK:
@@ -215,6 +217,22 @@ def read_params(root, chain):
     out = np.zeros((n.value, nv.value))
     L.tamcmc_outputs_read_params(str(root).encode(), int(chain), _p(out), n.value, C.byref(n), C.byref(nc), C.byref(nv))
     return out
+
+
+def run_packed(samplers, n_iter, record=True, stats=False):
+    """Several stars at once (tamcmc_sampler_run_packed): every sampler advances n_iter iterations, one host thread each inside the
+    library; the samplers must sit on different contexts (which may share a GPU).  Returns ([samples_k], [stats_k])."""
+    L = _rebind()
+    n_iter, S = int(n_iter), len(samplers)
+    smp = [np.zeros((n_iter, s.nchains, s.nvars)) if record else None for s in samplers]
+    stt = [np.zeros((n_iter, s.nchains, 3)) if stats else None for s in samplers]
+    hs = (_vp * S)(*[s._h for s in samplers])
+    ps = (_dp * S)(*[_p(a) for a in smp])
+    pt = (_dp * S)(*[_p(a) for a in stt])
+    rc = L.tamcmc_sampler_run_packed(hs, S, n_iter, ps, pt)
+    if rc != OK:
+        raise TamcmcError(rc, "tamcmc_sampler_run_packed: " + "; ".join(L.tamcmc_hip_last_error(s.ctx._h).decode() for s in samplers))
+    return smp, stt
 
 
 def params_summary(samples2d):

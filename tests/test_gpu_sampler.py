@@ -199,3 +199,48 @@ def test_checkpoint_and_resume(pkg, oracle, synth, ctx, tmp_path, engine):
     mu_b, cov_b = pkg.Sampler(ctx, star, **kw).get_proposal(1)
     assert not np.allclose(cov_r, cov_b)     # the adapted covariance replaced the initial diagonal one
     a.close(); b.close(); c.close()
+
+
+@pytest.mark.parametrize("engine,groups", [("device", 1), ("device", 2), ("host", 0)])
+def test_packed_stars_reproduce_their_solo_runs(pkg, oracle, synth, engine, groups):
+    """Several stars co-resident on one GPU (tamcmc_sampler_run_packed: one context and one host thread per star).  The stars share
+    nothing, so each one's samples and statistics must be bit-identical to a run on its own -- with adaptation running, for both
+    engines, and with the chains of a star in one or two stream groups."""
+    from tamcmc_c_amd import sampler as S
+    stars = []
+    for k, (nx, seed) in enumerate(((4000, 5), (3000, 6), (5000, 7))):
+        st = _star_with_data(pkg, oracle, synth, nx=nx, seed=seed)
+        stars.append(st)
+
+    def build():
+        cs, ss = [], []
+        for k, st in enumerate(stars):
+            c = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+            c.set_spectrum(st.x, st.y)
+            cs.append(c)
+            ss.append(pkg.Sampler(c, st, engine=engine, nchains=4 + 2 * k, lambda_temp=1.5, seed=40 + k, Nt_learn=(20, 160), periods_learn=(1,),
+                                  chain_groups=groups))
+        return cs, ss
+
+    n = 240
+    cs, ss = build()
+    solo = [s.run(n, stats=True) for s in ss]
+    for s in ss:
+        s.close()
+    for c in cs:
+        c.close()
+    cs, ss = build()
+    smp, stt = S.run_packed(ss, n, stats=True)
+    for k in range(len(stars)):
+        assert np.array_equal(smp[k], solo[k][0]) and np.array_equal(stt[k], solo[k][1]), k
+        assert ss[k].state()["iteration"] == n and (smp[k][1:, 0] != smp[k][:-1, 0]).any()
+    with pytest.raises(pkg.TamcmcError):
+        S.run_packed([ss[0], ss[0]], 1)                                          # one sampler twice
+    twin = pkg.Sampler(cs[0], stars[0], engine=engine, nchains=4, lambda_temp=1.5, seed=1, Nt_learn=(20, 160), periods_learn=(1,))
+    with pytest.raises(pkg.TamcmcError):
+        S.run_packed([ss[0], twin], 1)                                           # two samplers on one context
+    twin.close()
+    for s in ss:
+        s.close()
+    for c in cs:
+        c.close()
