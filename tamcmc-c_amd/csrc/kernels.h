@@ -17,6 +17,7 @@ struct LoglikeArgs {
     double x0, step;      // regular grid: x[i] = x0 + i*step (far-field tile geometry)
     int B;                // evaluations in this launch
     int ntiles;           // filled by launch_loglike
+    int probe = 0;        // tools/phase_probe.py only (TAMCMC_PROBE_SKIP): bit mask of kernel phases to skip -- results are then wrong
     int tile_rot = 0;     // tile dispatched first (launch order wraps around); any value in [0, ntiles) gives the same results
     const tamcmc_multiplet *mults;  // concatenated multiplet tables
     const int32_t *offsets;         // [2B] (begin,end) multiplet range per evaluation

@@ -61,7 +61,7 @@ struct __attribute__((aligned(16))) LdsMult {
     double asym;  // asymmetry coefficient
     double c2sq;  // (0.5*gamma*asym/fc)^2
     double fcx;   // STRICT: nu_c             FAST: asym/nu_c
-    double2 nh[7];  // {nu_nlm, H*V_m}
+    double2 nh[7];  // STRICT: {nu_nlm, H*V_m}   FAST: {A_m = (nu_nlm - x_c) 2/gamma, H*V_m}  (x_c = centre of the nominal tile)
 };
 
 // v_rcp_f64 seed (2^-24.4) + ONE Newton-Raphson step: relative error <= 2.1e-15
@@ -151,13 +151,15 @@ __device__ __forceinline__ void strict_mult(const LdsMult &M, const double (&xv)
 
 // ---- FAST: sum_m hv_m/q_m over a common denominator: 3 ops per component for q_m, 3 for (N,D),
 //      ONE reciprocal (+1 Newton step) per multiplet per bin ----
+//      The argument of component m is t = (x - nu_m) 2/gamma = (x - x_c) 2/gamma - A_m with A_m staged per tile: one fma per
+//      component from the bin's offset to the tile centre (|x - x_c| <= half a tile, so the fma's rounding is ~1e-15 of t's scale).
 template <int NM, int K, bool FULL>
-__device__ __forceinline__ void fast_mult(const LdsMult &M, const double (&xv)[K], const int (&bin)[K], double (&acc)[K]) {
-    double nu[NM], hv[NM];
+__device__ __forceinline__ void fast_mult(const LdsMult &M, const double (&xv)[K], const int (&bin)[K], double (&acc)[K], double xc) {
+    double nA[NM], hv[NM];
 #pragma unroll
     for (int m = 0; m < NM; m++) {
         const double2 p = M.nh[m];
-        nu[m] = p.x;
+        nA[m] = -p.x;
         hv[m] = p.y;
     }
     const double g = M.g;
@@ -170,12 +172,13 @@ __device__ __forceinline__ void fast_mult(const LdsMult &M, const double (&xv)[K
         for (int k = 0; k < K; k++) {
             if (FULL || (bin[k] >= i0 && bin[k] < i1)) {
                 const double xx = xv[k];
-                double t = (xx - nu[0]) * g;
+                const double dx = xx - xc;
+                double t = fma(dx, g, nA[0]);
                 double D = fma(t, t, 1.0);
                 double N = hv[0];
 #pragma unroll
                 for (int m = 1; m < NM; m++) {
-                    t = (xx - nu[m]) * g;
+                    t = fma(dx, g, nA[m]);
                     const double q = fma(t, t, 1.0);
                     N = fma(N, q, hv[m] * D);
                     D = D * q;
@@ -194,10 +197,11 @@ __device__ __forceinline__ void fast_mult(const LdsMult &M, const double (&xv)[K
         for (int k = 0; k < K; k++) {
             if (FULL || (bin[k] >= i0 && bin[k] < i1)) {
                 const double xx = xv[k];
+                const double dx = xx - xc;
                 double res = 0.0;
 #pragma unroll
                 for (int m = 0; m < NM; m++) {
-                    const double t = (xx - nu[m]) * g;
+                    const double t = fma(dx, g, nA[m]);
                     res = res + hv[m] / fma(t, t, 1.0);
                 }
                 if (flags & F_ASYM) {
@@ -211,12 +215,12 @@ __device__ __forceinline__ void fast_mult(const LdsMult &M, const double (&xv)[K
 }
 
 template <bool FAST, int NM, int K>
-__device__ __forceinline__ void mult_dispatch(const LdsMult &M, const double (&xv)[K], const int (&bin)[K], double (&acc)[K]) {
+__device__ __forceinline__ void mult_dispatch(const LdsMult &M, const double (&xv)[K], const int (&bin)[K], double (&acc)[K], double xc) {
     if (M.flags & F_FULL) {
-        if (FAST) fast_mult<NM, K, true>(M, xv, bin, acc);
+        if (FAST) fast_mult<NM, K, true>(M, xv, bin, acc, xc);
         else strict_mult<NM, K, true>(M, xv, bin, acc);
     } else {
-        if (FAST) fast_mult<NM, K, false>(M, xv, bin, acc);
+        if (FAST) fast_mult<NM, K, false>(M, xv, bin, acc, xc);
         else strict_mult<NM, K, false>(M, xv, bin, acc);
     }
 }
@@ -271,6 +275,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         }
     }
 
+    tamcmc_multiplet g;
     const int mbeg = a.offsets[2 * b], mend = a.offsets[2 * b + 1];
     // prebuilt background series of this (evaluation, tile): issued now, stored to LDS when the tile polynomial is set up
     double bg_pre = 0.0;
@@ -278,7 +283,6 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         const int hl0 = (WGS > 64) ? tid - 64 : tid;
         if (FARFIELD && !DELTA && a.bg_poly && hl0 >= 0 && hl0 < NH) bg_pre = a.bg_poly[((size_t)b * a.ntiles + tile) * NH + hl0];
     }
-    tamcmc_multiplet g;
     double xv[K], yv[K], acc[K];
     int bin[K];
 #pragma unroll
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
             const int idx = c0 + tid;
             g = a.mults[min(idx, mend - 1)];  // the whole row in ONE round trip (clamped index: lanes past the end stage nothing)
             const int i0 = g.i0, i1 = g.i1;
-            const bool ov = (idx < mend) && (i0 < t1) && (i1 > t0);
+            const bool ov = (idx < mend) && (i0 < t1) && (i1 > t0) && !(a.probe & 16);
             const unsigned long long mask = __ballot(ov);
             bool far = false;
             if (ov) {
@@ -365,31 +369,34 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                 const bool full = (i0 <= t0 && i1 >= t1);
                 if (full) flags |= F_FULL;
                 if (g.asym != 0.0) flags |= F_ASYM;
-                const double c2 = 0.5 * g.gamma * g.asym / g.fc;
+                // FAST: reciprocal + Newton steps instead of the two IEEE divides by nu_c (exact zeros when asym = 0 either way)
+                const double ifc = FAST ? rcp_nr2(g.fc) : 0.0;
+                const double c2 = FAST ? 0.5 * g.gamma * g.asym * ifc : 0.5 * g.gamma * g.asym / g.fc;
                 d.c2sq = c2 * c2;
                 d.asym = g.asym;
+                double Am[7];
                 if (FAST) {
                     const double ig = 2.0 * rcp_nr2(g.gamma);
                     d.g = ig;
-                    d.fcx = g.asym / g.fc;
+                    d.fcx = g.asym * ifc;
+#pragma unroll
+                    for (int m = 0; m < 7; m++) Am[m] = ig * (g.nu[m] - xc);  // constant trip count: g stays in registers
                     if (FARFIELD && full) {
                         const double beta2 = (ig * h) * (ig * h);
                         const double r2 = (g.asym != 0.0) ? RHO_MAX2_ASYM : RHO_MAX2;
                         far = true;
 #pragma unroll
-                        for (int m = 0; m < 7; m++) {  // constant trip count: g stays in registers
-                            const double A = ig * (g.nu[m] - xc);
-                            if (m < nm && !(beta2 <= r2 * fma(A, A, 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
-                        }
+                        for (int m = 0; m < 7; m++)
+                            if (m < nm && !(beta2 <= r2 * fma(Am[m], Am[m], 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
                     }
                     if (far) flags |= F_FAR;
                     else {
                         // prod_m (1 + ((x-nu_m) ig)^2) < (1e38)^7 = 1e266 on the whole tile?
-                        const double xlo = xc - h, xhi = xc + h;  // the nominal tile on the regular grid (a coarse bound)
+                        const double bh = ig * h;  // |t| <= |A_m| + beta on the nominal tile (a coarse bound)
                         bool safe = true;
 #pragma unroll
                         for (int m = 0; m < 7; m++) {
-                            const double dm = fmax(fabs(xlo - g.nu[m]), fabs(xhi - g.nu[m])) * ig;
+                            const double dm = fabs(Am[m]) + bh;
                             if (m < nm && !(fma(dm, dm, 1.0) < 1e38)) safe = false;  // also false for NaN/inf inputs
                         }
                         if (safe) flags |= F_SAFE;
@@ -400,7 +407,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                 }
                 d.i0 = i0; d.i1 = i1; d.l = l; d.flags = flags;
 #pragma unroll
-                for (int m = 0; m < 7; m++) d.nh[m] = make_double2(g.nu[m], g.hv[m]);
+                for (int m = 0; m < 7; m++) d.nh[m] = make_double2(FAST ? Am[m] : g.nu[m], g.hv[m]);
             }
             if (FARFIELD) {
                 // far components packed densely (no idle lanes for l < 3): offset = components of the far multiplets before this lane
@@ -423,19 +430,19 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
         }
         __syncthreads();
         KSTAMP(2);
-        const int n = s_n;
+        const int n = (a.probe & 1) ? 0 : s_n;
         for (int q = 0; q < n; q++) {
             const LdsMult &M = s_m[q];
             if (FARFIELD && (M.flags & F_FAR)) continue;  // wave-uniform
             switch (M.l) {  // wave-uniform
-            case 0: mult_dispatch<FAST, 1, K>(M, xv, bin, acc); break;
-            case 1: mult_dispatch<FAST, 3, K>(M, xv, bin, acc); break;
-            case 2: mult_dispatch<FAST, 5, K>(M, xv, bin, acc); break;
-            default: mult_dispatch<FAST, 7, K>(M, xv, bin, acc); break;
+            case 0: mult_dispatch<FAST, 1, K>(M, xv, bin, acc, xc); break;
+            case 1: mult_dispatch<FAST, 3, K>(M, xv, bin, acc, xc); break;
+            case 2: mult_dispatch<FAST, 5, K>(M, xv, bin, acc, xc); break;
+            default: mult_dispatch<FAST, 7, K>(M, xv, bin, acc, xc); break;
             }
         }
         KSTAMP(3);
-        if (FARFIELD && s_nfar > 0) {  // workgroup-uniform
+        if (FARFIELD && s_nfar > 0 && !(a.probe & 2)) {  // workgroup-uniform
             // AFTER the near-field loop (its registers are dead): one lane per (far multiplet, m) slot computes the NC Taylor
             // coefficients of its component; the lanes' vectors are summed in a fixed order into the tile polynomial
             double fcoef[NC];
@@ -448,7 +455,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                 {
                     const double2 nhm = M.nh[e & 7];
                     const double beta = M.g * h;
-                    const double A = M.g * (nhm.x - xc);
+                    const double A = nhm.x;
                     const double inv = rcp_nr2(fma(A, A, 1.0));
                     const double two_req = 2.0 * beta * A * inv, q2 = beta * beta * inv;
                     double cm = nhm.y * inv;      // c_0
@@ -509,7 +516,7 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
     for (int k = 0; k < K; k++) yv[k] = a.y[min(bin[k], a.Nx - 1)];
     if (FAST) __syncthreads();  // s_lt / s_coef visible (also when the evaluation has no multiplet chunk)
     if (FARFIELD) {
-        if (s_anyfar) {  // workgroup-uniform: far multiplets and/or the background series
+        if (s_anyfar && !(a.probe & 4)) {  // workgroup-uniform: far multiplets and/or the background series
             const double inv_h = 1.0 / h;
 #pragma unroll
             for (int k = 0; k < K; k++) {
@@ -576,8 +583,11 @@ __global__ void __launch_bounds__(WGS) k_loglike(const LoglikeArgs a) {
                     s[1] = s[1] + ((fabs(dl) < 1e-4) ? dl * fma(dl, fma(dl, 1.0 / 3.0, -0.5), 1.0) : log1p(dl));
                 }
             } else if (valid) {
-                s[0] = fma(yv[k], rcp_nr2(Mv), s[0]);
-                prod = prod * Mv;
+                if (a.probe & 8) s[0] = s[0] + yv[k] * Mv;
+                else {
+                    s[0] = fma(yv[k], rcp_nr2(Mv), s[0]);
+                    prod = prod * Mv;
+                }
             }
         }
         Mk[k] = Mv;
