@@ -36,10 +36,10 @@ namespace rgb {
 constexpr int MAXP = 32;      // p modes per vector (fmax-fmin+2 Dnu)/Dnu + margins
 constexpr int MAXSOL = 1024;  // mixed modes per vector before de-duplication
 constexpr int WG = 256;
-constexpr int SEG = 12;        // workgroups per (vector, p mode): each scans one segment of the grid and refines its own candidates
 
 struct Prep {  // one parameter vector's solver inputs
     int Lp, Lg, ng_min, status;
+    int probe_dense, pad_;         // TAMCMC_ARMM_DENSE=1: walk the whole grid (the reference's way) instead of the pole-structured scan
     int ig0[MAXP];                 // first g mode inside the zone of p mode ip, -1: none (the reference skips the pair)
     double nu_p[MAXP], dnu_loc[MAXP], dnup[MAXP];
     double Dnu_p, DPl, alpha, q, zone, resol, fact, keep_lo, keep_hi;
@@ -70,9 +70,21 @@ __device__ __forceinline__ bool changes_sign(double a, double b) {  // sign_chan
     return ((b >= 0 && a < 0) || (b > 0 && a <= 0)) || (b <= 0 && a >= 0);
 }
 
-// SEG workgroups per (vector b, p mode ip).
-__global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sols, int *nsol) {
-    const int b = blockIdx.y, ip = blockIdx.x / SEG, seg = blockIdx.x % SEG, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One wave per (vector b, p mode ip): solver_mm.cpp:330-406 for that pair.
+//  scan  : candidate = grid index i with a sign change of p-g between grid points i and i+1 (the reference walks the whole grid).
+//          p-g has a simple structure: tan X has its poles where kappa(nu) = 1e6/DPl (1/nu - 1/nu_g) - 1/2 is an integer; at a pole p-g
+//          drops by Dl, between two poles it is continuous and strictly increasing (nu - nu_p increases, X decreases).  So the cells
+//          with a sign change are at most ONE per pole-free stretch -- found by bisection on the grid index (the same grid points, ~11
+//          evaluations instead of hundreds) -- and the three cells around each pole, which are evaluated directly (the pole's own
+//          cell changes sign when the drop crosses zero; one cell of margin on each side absorbs the rounding of the pole position).
+//          One LANE per unit: unit 0 = the stretch before the first pole, unit j+1 = pole j and the stretch after it.  Windows that
+//          start at nu = 0 or hold an unreasonable number of poles take the dense walk (TAMCMC_ARMM_DENSE=1 forces it).
+//  refine: one LANE per candidate: the local grid of step resol*fact over [x0 - 2 resol, x0 + 2 resol], lin_interpol with x = p-g,
+//          y = nu at 0 (interpol.cpp:13-43), the 0.1 % ratio test.  Without a pole inside the window p-g is increasing there and the
+//          bracketing pair is found by bisection; the rare windows that hold both a bracket and a pole are walked point by point by
+//          the whole wave afterwards, like the reference does.
+__global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sols, int *nsol) {
+    const int b = blockIdx.y, ip = blockIdx.x, lane = threadIdx.x;
     const Prep &P = preps[b];
     if (ip >= P.Lp || P.status != 0 || P.ig0[ip] < 0) return;
     const double nu_p = P.nu_p[ip], Dl = P.dnu_loc[ip], nu_g = nu_g_of(P, P.ig0[ip]);
@@ -84,103 +96,155 @@ __global__ void __launch_bounds__(WG) k_armm_scan(const Prep *preps, double *sol
     if (n < 2) return;
     const double step = (numax - lo) / (double)(n - 1);
     auto grid = [&](long i) { return (i == n - 1) ? numax : lo + (double)i * step; };
-    __shared__ long s_cand[512];
-    __shared__ int s_nc;
-    if (tid == 0) s_nc = 0;
+    auto fg = [&](long i) { return f_pg(grid(i), nu_p, nu_g, Dl, P.DPl, P.q); };
+    constexpr int MAXC = 1024;
+    __shared__ long s_cand[MAXC];
+    __shared__ int s_hard[MAXC];
+    __shared__ int s_nc, s_nh;
+    if (lane == 0) { s_nc = 0; s_nh = 0; }
     __syncthreads();
-    // ---- scan: candidate = index i with a sign change between grid points i and i+1.  Each lane evaluates ONE point; its right
-    //      neighbour's value comes from the next lane (the last lane of a wave evaluates that one point more)
-    const long seg_lo = (n - 1) * seg / SEG, seg_hi = (n - 1) * (seg + 1) / SEG;  // pairs (i, i+1) with seg_lo <= i < seg_hi
-    for (long i0 = seg_lo; i0 < seg_hi; i0 += WG) {
-        const long i = i0 + tid;
-        const double fa = (i < n) ? f_pg(grid(i), nu_p, nu_g, Dl, P.DPl, P.q) : 0.0;
-        double fb = __shfl_down(fa, 1, 64);
-        if (lane == 63 && i + 1 < n) fb = f_pg(grid(i + 1), nu_p, nu_g, Dl, P.DPl, P.q);
-        if (i < seg_hi && changes_sign(fa, fb)) {
-            const int k = atomicAdd(&s_nc, 1);
-            if (k < 512) s_cand[k] = i;
+    auto push = [&](long i) {
+        const int k = atomicAdd(&s_nc, 1);
+        if (k < MAXC) s_cand[k] = i;
+    };
+    const double kap_scale = 1e6 / P.DPl, inv_g = 1. / nu_g;
+    const double k_hi = kap_scale * (1. / lo - inv_g) - 0.5, k_lo = kap_scale * (1. / numax - inv_g) - 0.5;
+    const bool structured = (lo > 0) && isfinite(k_hi) && isfinite(k_lo) && (k_hi - k_lo) < 1.0e5 && P.q > 0 && Dl > 0 && !P.probe_dense;
+    if (structured) {
+        const long kmax = (long)floor(k_hi) + 1, kmin = (long)ceil(k_lo) - 1;  // one pole beyond each end: harmless, clipped below
+        const long np = kmax - kmin + 1;
+        auto pole_cell = [&](long j) -> long {  // cell holding pole j (poles in ascending frequency), clipped to [-3, n+1]
+            const double nu_k = 1. / (inv_g + ((double)(kmax - j) + 0.5) / kap_scale);
+            double c = floor((nu_k - lo) / step);
+            if (!(c > -3.0)) c = -3.0;
+            if (!(c < (double)(n + 1))) c = (double)(n + 1);
+            return (long)c;
+        };
+        for (long u = lane; u <= np; u += 64) {
+            long a, e;  // the pole-free stretch of this unit: cells with left index a .. e
+            if (u == 0) { a = 0; e = pole_cell(0) - 2; }
+            else {
+                const long j = u - 1, cj = pole_cell(j);
+                const long prev_end = (j > 0) ? pole_cell(j - 1) + 1 : -1;  // last cell of the previous pole's zone
+                for (long i = (cj - 1 > prev_end ? cj - 1 : prev_end + 1); i <= cj + 1; i++)
+                    if (i >= 0 && i <= n - 2 && changes_sign(fg(i), fg(i + 1))) push(i);
+                a = cj + 2;
+                e = (j + 1 < np) ? pole_cell(j + 1) - 2 : n - 2;
+            }
+            if (a < 0) a = 0;
+            if (e > n - 2) e = n - 2;
+            if (a > e) continue;
+            const double fa = fg(a), fe = fg(e + 1);
+            if (fa > 0.0 || fe < 0.0) continue;      // increasing and of one sign: no change in this stretch
+            if (!(fa < 0.0)) { push(a); continue; }  // an exact zero on the first point
+            long lo_i = a, hi_i = e + 1;             // f[lo_i] < 0 <= f[hi_i]
+            while (hi_i - lo_i > 1) {
+                const long mid = lo_i + (hi_i - lo_i) / 2;
+                if (fg(mid) >= 0.0) hi_i = mid; else lo_i = mid;
+            }
+            push(lo_i);
+        }
+    } else {
+        // dense walk: each lane evaluates ONE point per pass; its right neighbour's value comes from the next lane (lane 63
+        // evaluates that one point more)
+        for (long i0 = 0; i0 < n - 1; i0 += 64) {
+            const long i = i0 + lane;
+            const double fa = (i < n) ? fg(i) : 0.0;
+            double fb = __shfl_down(fa, 1, 64);
+            if (lane == 63 && i + 1 < n) fb = fg(i + 1);
+            if (i < n - 1 && changes_sign(fa, fb)) push(i);
         }
     }
     __syncthreads();
-    if (s_nc > 512) {  // more sign changes than the candidate list holds: flag the vector (the host reports it), do not guess
-        if (tid == 0) atomicAdd(&nsol[b], 2 * MAXSOL);
+    if (s_nc > MAXC) {  // more sign changes than the candidate list holds: flag the vector (the host reports it), do not guess
+        if (lane == 0) atomicAdd(&nsol[b], 2 * MAXSOL);
         return;
     }
     const int nc = s_nc;
-    // ---- refine: one wave per candidate (solver_mm.cpp:378-406 + lin_interpol of interpol.cpp with x = p-g, y = nu)
-    for (int c = wave; c < nc; c += WG / 64) {
-        const double x0 = grid(s_cand[c]);
-        const double rmin = x0 - 2 * P.resol, rmax = x0 + 2 * P.resol;
-        const long nl = (long)((rmax - rmin) / (P.resol * P.fact));
-        if (nl < 2) continue;
-        const double ls = (rmax - rmin) / (double)(nl - 1);
-        auto lg = [&](long j) { return (j == nl - 1) ? rmax : rmin + (double)j * ls; };
-        auto fl = [&](long j) { return f_pg(lg(j), nu_p, nu_g, Dl, P.DPl, P.q); };
-        const double f_first = fl(0), f_last = fl(nl - 1);
+    struct Local {  // the local grid of one candidate
+        double rmin, rmax, ls;
+        long nl;
+    };
+    auto local_of = [&](long cand) {
+        Local L;
+        const double x0 = grid(cand);
+        L.rmin = x0 - 2 * P.resol; L.rmax = x0 + 2 * P.resol;
+        L.nl = (long)((L.rmax - L.rmin) / (P.resol * P.fact));
+        L.ls = L.nl >= 2 ? (L.rmax - L.rmin) / (double)(L.nl - 1) : 0.0;
+        return L;
+    };
+    auto lg = [&](const Local &L, long j) { return (j == L.nl - 1) ? L.rmax : L.rmin + (double)j * L.ls; };
+    auto fl = [&](const Local &L, long j) { return f_pg(lg(L, j), nu_p, nu_g, Dl, P.DPl, P.q); };
+    // straight line through two local points evaluated at p-g = 0, then the ratio test (solver_mm.cpp:392-404)
+    auto finish = [&](const Local &L, long best, double f_first, double f_last) {
+        double a = 0, bb = 0;
+        if (0.0 >= f_first && 0.0 <= f_last) {
+            const long j = best < L.nl - 1 ? best : L.nl - 2;
+            const double fa = fl(L, j), fb = fl(L, j + 1);
+            a = (lg(L, j + 1) - lg(L, j)) / (fb - fa);
+            bb = lg(L, j) - a * fa;
+        }
+        if (0.0 < f_first) {
+            a = (lg(L, 1) - lg(L, 0)) / (fl(L, 1) - f_first);
+            bb = lg(L, 0) - a * f_first;
+        }
+        if (0.0 > f_last) {
+            const double fa = fl(L, L.nl - 2);
+            a = (lg(L, L.nl - 1) - lg(L, L.nl - 2)) / (f_last - fa);
+            bb = lg(L, L.nl - 2) - a * fa;
+        }
+        const double prop = a * 0.0 + bb;
+        const double PI = 3.141592653589793238;
+        const double X = PI * (1. / prop - 1. / nu_g) * 1e6 / P.DPl;
+        const double ratio = (Dl * atan(P.q * tan(X)) / PI) / (prop - nu_p);
+        if (ratio >= 0.999 && ratio <= 1.001 && prop >= P.keep_lo && prop <= P.keep_hi) {
+            const int k = atomicAdd(&nsol[b], 1);
+            if (k < MAXSOL) sols[(size_t)b * MAXSOL + k] = prop;
+        }
+    };
+    for (int c = lane; c < nc; c += 64) {
+        const Local L = local_of(s_cand[c]);
+        if (L.nl < 2) continue;
+        const double f_first = fl(L, 0), f_last = fl(L, L.nl - 1);
         // first j with f[j] <= 0 <= f[j+1] -- only needed when lin_interpol interpolates (f_first <= 0 <= f_last); otherwise it
         // extrapolates from the first or last two points (a pole of tan(): half of all candidates) and no search is made
-        long best = nl;
+        long best = L.nl;
         if (!(0.0 < f_first) && !(0.0 > f_last)) {
-            // poles of tan X sit where kappa(nu) = 1e6/DPl (1/nu - 1/nu_g) is a half-integer; without one inside the window p-g is
-            // continuous and increasing there, so the first bracketing segment is THE sign change: 64-ary search, two rounds
-            const double ka = 1e6 / P.DPl * (1. / rmin - 1. / nu_g) - 0.5, kb = 1e6 / P.DPl * (1. / rmax - 1. / nu_g) - 0.5;
+            const double ka = kap_scale * (1. / L.rmin - inv_g) - 0.5, kb = kap_scale * (1. / L.rmax - inv_g) - 0.5;
             const bool pole_inside = (floor(ka) != floor(kb)) || fabs(ka - rint(ka)) < 1e-9 || fabs(kb - rint(kb)) < 1e-9;
-            if (!pole_inside) {
-                long lo_j = 0, hi_j = nl - 1;  // invariant: f[lo_j] <= 0 <= f[hi_j]
-                while (hi_j - lo_j > 1) {
-                    const long span = hi_j - lo_j, stride = (span + 63) / 64;
-                    const long j = lo_j + (long)lane * stride;
-                    const bool neg = (j < hi_j) ? (fl(j) <= 0.0) : false;   // lanes beyond the interval count as "positive side"
-                    const unsigned long long m = __ballot(neg);
-                    const int last_neg = 63 - __clzll((long long)m);           // lane 0 is always on the negative side (f[lo_j] <= 0)
-                    const long nlo = lo_j + (long)last_neg * stride;
-                    long nhi = nlo + stride;
-                    if (nhi > hi_j) nhi = hi_j;
-                    lo_j = nlo; hi_j = nhi;
-                }
-                // the segment [lo_j, lo_j+1] has f[lo_j] <= 0 and f[lo_j+1] >= 0 up to the strictness of the two tests: step back
-                // over exact zeros so that the FIRST segment satisfying f[j] <= 0 <= f[j+1] is returned
-                best = lo_j;
-                while (best > 0 && fl(best - 1) <= 0.0 && fl(best) >= 0.0 && !(fl(best) > 0.0)) best--;
-            } else {
-                for (long j0 = 0; j0 < nl - 1; j0 += 64) {
-                    const long j = j0 + lane;
-                    bool hit = false;
-                    if (j < nl - 1) {
-                        const double fa = fl(j), fb = fl(j + 1);
-                        hit = !(0.0 < fa || 0.0 > fb);  // the loop condition of lin_interpol, negated
-                    }
-                    const unsigned long long m = __ballot(hit);
-                    if (m) { best = j0 + (long)(__ffsll((long long)m) - 1); break; }
-                }
+            if (pole_inside) {  // left to the whole wave below
+                const int k = atomicAdd(&s_nh, 1);
+                s_hard[k] = c;
+                continue;
             }
+            long lo_j = 0, hi_j = L.nl - 1;  // f[lo_j] <= 0 <= f[hi_j], p-g increasing: the last point with f <= 0
+            while (hi_j - lo_j > 1) {
+                const long mid = lo_j + (hi_j - lo_j) / 2;
+                if (fl(L, mid) <= 0.0) lo_j = mid; else hi_j = mid;
+            }
+            // step back over exact zeros so that the FIRST pair with f[j] <= 0 <= f[j+1] is the one used
+            best = lo_j;
+            while (best > 0 && fl(L, best - 1) <= 0.0 && fl(L, best) >= 0.0 && !(fl(L, best) > 0.0)) best--;
         }
-        if (lane == 0) {
-            double a = 0, bb = 0;
-            if (0.0 >= f_first && 0.0 <= f_last) {
-                const long j = best < nl - 1 ? best : nl - 2;
-                const double fa = fl(j), fb = fl(j + 1);
-                a = (lg(j + 1) - lg(j)) / (fb - fa);
-                bb = lg(j) - a * fa;
+        finish(L, best, f_first, f_last);
+    }
+    __syncthreads();
+    const int nh = s_nh;
+    for (int hc = 0; hc < nh; hc++) {  // wave-uniform
+        const Local L = local_of(s_cand[s_hard[hc]]);
+        const double f_first = fl(L, 0), f_last = fl(L, L.nl - 1);
+        long best = L.nl;
+        for (long j0 = 0; j0 < L.nl - 1; j0 += 64) {
+            const long j = j0 + lane;
+            bool hit = false;
+            if (j < L.nl - 1) {
+                const double fa = fl(L, j), fb = fl(L, j + 1);
+                hit = !(0.0 < fa || 0.0 > fb);  // the loop condition of lin_interpol, negated
             }
-            if (0.0 < f_first) {
-                a = (lg(1) - lg(0)) / (fl(1) - f_first);
-                bb = lg(0) - a * f_first;
-            }
-            if (0.0 > f_last) {
-                const double fa = fl(nl - 2);
-                a = (lg(nl - 1) - lg(nl - 2)) / (f_last - fa);
-                bb = lg(nl - 2) - a * fa;
-            }
-            const double prop = a * 0.0 + bb;
-            const double PI = 3.141592653589793238;
-            const double X = PI * (1. / prop - 1. / nu_g) * 1e6 / P.DPl;
-            const double ratio = (Dl * atan(P.q * tan(X)) / PI) / (prop - nu_p);
-            if (ratio >= 0.999 && ratio <= 1.001 && prop >= P.keep_lo && prop <= P.keep_hi) {
-                const int k = atomicAdd(&nsol[b], 1);
-                if (k < MAXSOL) sols[(size_t)b * MAXSOL + k] = prop;
-            }
+            const unsigned long long m = __ballot(hit);
+            if (m) { best = j0 + (long)(__ffsll((long long)m) - 1); break; }
         }
+        if (lane == 0) finish(L, best, f_first, f_last);
     }
 }
 
@@ -554,6 +618,8 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
                      int *per_out, int *stride_out, int *first_err, int *tile_rot_out) {
     using namespace rgb;
     const bool cte_width = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4_ID);
+    const char *env_dense = getenv("TAMCMC_ARMM_DENSE");
+    const bool dense_scan = env_dense && atoi(env_dense) != 0;
     const double *hx = c->hx.data();
     const int64_t Nx = c->Nx;
     const double step = hx[2] - hx[1];  // models.cpp:4719
@@ -590,6 +656,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
         }
         status[b] = st;
         P[(size_t)b].status = st;
+        P[(size_t)b].probe_dense = dense_scan ? 1 : 0;
         ri.status = st;
         if (st == TAMCMC_OK) {
             ri.Nfl0 = u.Nfl0; ri.Nfl2 = u.Nfl2; ri.Nfl3 = u.Nfl3; ri.lmax = u.lmax; ri.do_amp = u.do_amp ? 1 : 0; ri.cte_width = cte_width ? 1 : 0;
@@ -634,7 +701,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     HIPCHK(c, hipMemcpyAsync(d_prep, P.data(), (size_t)B * sizeof(Prep), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_rows, R.data(), (size_t)B * sizeof(RowIn), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(d_norm, 0, (size_t)B * (sizeof(unsigned long long) + 2 * sizeof(int)), st));
-    hipLaunchKernelGGL(k_armm_scan, dim3(MAXP * SEG, B), dim3(WG), 0, st, d_prep, d_sols, d_nsol);
+    hipLaunchKernelGGL(k_armm_scan, dim3(MAXP, B), dim3(64), 0, st, d_prep, d_sols, d_nsol);
     hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_rows, d_sols, d_nsol, d_fl1);
     const int chunks = 64;
     hipLaunchKernelGGL(k_zeta, dim3(chunks, B), dim3(WG), 0, st, d_prep, d_fl1, d_nsol, d_ksi, d_norm, chunks);

@@ -84,3 +84,35 @@ def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth, cte):
     with pytest.raises(pkg.TamcmcError):
         pkg.Sampler(ctx, star, nchains=4, engine="device")
     ctx.close()
+
+
+def test_structured_scan_finds_the_cells_of_the_dense_walk(pkg, synth, monkeypatch):
+    """The mixed-mode solver's first pass looks for grid cells where p(nu) - g(nu) changes sign.  The reference walks every grid
+    point (solver_mm.cpp:330-376); the device scan uses the function's structure instead (poles of tan in closed form, bisection on
+    the grid index between them: csrc/rgb_prestep.hip).  Both must deliver the same cells, hence bit-identical model rows -- over
+    period spacings, couplings, both solver drivers and all bias types, including a coarse and a fine frequency grid."""
+    rng = np.random.default_rng(17)
+    cases = []
+    for k in range(10):
+        cases.append(dict(DPl=float(rng.uniform(60, 320)), q=float(rng.uniform(0.05, 0.6)), dnu=float(rng.uniform(8, 22)),
+                          model_type=k % 2, bias_type=k % 3, alpha_g=float(rng.uniform(0, 0.5)), step=(0.05 if k % 4 else 0.011)))
+    for c in cases:
+        params, pl = synth.make_params_rgb_model(np.random.default_rng(3), dnu=c["dnu"], DPl=c["DPl"], q=c["q"], alpha_g=c["alpha_g"],
+                                                 model_type=c["model_type"], bias_type=c["bias_type"])
+        o = np.cumsum([0] + list(pl))
+        fl0 = params[o[2]:o[3]]
+        x = fl0.min() - 1.2 * c["dnu"] + c["step"] * np.arange(int((fl0.max() - fl0.min() + 2.4 * c["dnu"]) / c["step"]))
+        P = np.tile(params, (4, 1))
+        P[1:, o[3] + 1] *= 1 + 0.01 * rng.standard_normal(3)
+        P[1:, o[3]] += 0.05 * rng.standard_normal(3)
+        ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+        ctx.set_spectrum(x, np.ones_like(x))
+        out = {}
+        for dense in ("1", "0"):
+            monkeypatch.setenv("TAMCMC_ARMM_DENSE", dense)
+            logL, rows, st = ctx.loglike_params_batch(pkg.MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4, P, pl, None, want_model=True)
+            assert (st == 0).all(), (c, st)
+            out[dense] = (logL, rows)
+        assert np.array_equal(out["0"][1], out["1"][1]), c
+        assert np.array_equal(out["0"][0], out["1"][0]), c
+        ctx.close()
