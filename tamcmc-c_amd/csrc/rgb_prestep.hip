@@ -254,11 +254,13 @@ __global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, cons
     __shared__ double s[MAXSOL];
     if (nsol[b] > MAXSOL) return;  // overflow flag: left for the host
     const int n = nsol[b];
-    for (int i = tid; i < MAXSOL; i += WG) s[i] = i < n ? sols[(size_t)b * MAXSOL + i] : INFINITY;
+    int N2 = 64;  // bitonic network over the next power of two (padding sorts to the end)
+    while (N2 < n) N2 <<= 1;
+    for (int i = tid; i < N2; i += WG) s[i] = i < n ? sols[(size_t)b * MAXSOL + i] : INFINITY;
     __syncthreads();
-    for (int k = 2; k <= MAXSOL; k <<= 1)
+    for (int k = 2; k <= N2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < MAXSOL; i += WG) {
+            for (int i = tid; i < N2; i += WG) {
                 const int l = i ^ j;
                 if (l > i) {
                     const bool up = (i & k) == 0;
@@ -268,20 +270,25 @@ __global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, cons
             }
             __syncthreads();
         }
-    if (tid == 0) {
+    __shared__ int s_m;
+    if (tid == 0) {  // std::unique keeps an element unless it is within tol of the last KEPT one: a serial chain, run in LDS (in place)
         const double tol = 2 * preps[b].resol;
         int m = 0;
-        for (int i = 0; i < n; i++)
-            if (m == 0 || !(fabs(sols[(size_t)b * MAXSOL + m - 1] - s[i]) <= tol)) sols[(size_t)b * MAXSOL + m++] = s[i];
+        double last = 0;
+        for (int i = 0; i < n; i++) {
+            const double v = s[i];
+            if (m == 0 || !(fabs(last - v) <= tol)) { s[m++] = v; last = v; }
+        }
         nsol[b] = m;
-        s[0] = (double)m;
+        s_m = m;
     }
     __syncthreads();
+    for (int i = tid; i < s_m; i += WG) sols[(size_t)b * MAXSOL + i] = s[i];
     // frequency bias of the mixed modes: spline through the (fref, ferr) nodes (models.cpp:4833-4842, :4873-4880; spline.h:476-498)
     const RowIn &R = rows_in[b];
-    const int m = (int)s[0];
+    const int m = s_m;
     for (int i = tid; i < m; i += WG) {
-        const double v = sols[(size_t)b * MAXSOL + i];
+        const double v = s[i];
         double bias = 0;
         if (R.bias_n >= 3) {
             const int nn = R.bias_n;
@@ -296,21 +303,24 @@ __global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, cons
     }
 }
 
-__device__ __forceinline__ double ksi_one(double nu, double nu_p, double nu_g, double Dnu_p, double DPl, double q) {  // bump_DP.cpp:46-78
-    const double PI = 3.14159265358979323846;
-    const double up = PI * 1e6 * (1. / nu - 1. / nu_g) / DPl;
-    const double down = PI * (nu - nu_p) / Dnu_p;
-    const double front = 1e-6 * nu * nu * DPl / (q * Dnu_p);
-    const double cu = cos(up), cd = cos(down);
-    return 1. / (1. + front * ((cu * cu) / (cd * cd)));
-}
+// One (p, g) term of the zeta function (bump_DP.cpp:46-78):
+//   1 / (1 + front cos^2(up)/cos^2(down)),  up = pi 1e6 (1/nu - 1/nu_g)/DPl,  down = pi (nu - nu_p)/Dnu_p,  front = 1e-6 nu^2 DPl/(q Dnu_p).
 // Sum over all (p, g) pairs.  cos^2 has period pi and the g ladder is regular (1e6/(nu_g DPl) = n_g + alpha), so the term does not
 // depend on WHICH g mode is used: the reference's inner loop over the g modes adds L_g copies of the same number (up to the
 // rounding of its argument, ~1e-13 relative); here it is evaluated once, with the ladder's middle mode, and multiplied.
+// The g-mode cosine and nu^2 DPl/q are common to all p modes; 1/(1 + front cu^2/cd^2) = cd^2/(cd^2 + front cu^2) (one division; the
+// limits cd -> 0 and front -> inf give the same 0, 0/0 the same NaN).
 __device__ __forceinline__ double ksi_sum(const Prep &P, double nu) {
+    const double PI = 3.14159265358979323846;
     const double nu_g = nu_g_of(P, P.Lg / 2);
+    const double cu = cos(PI * 1e6 * (1. / nu - 1. / nu_g) / P.DPl);
+    const double cu2 = cu * cu, fr = 1e-6 * nu * nu * P.DPl / P.q;
     double s = 0;
-    for (int ip = 0; ip < P.Lp; ip++) s += (double)P.Lg * ksi_one(nu, P.nu_p[ip], nu_g, P.dnup[ip], P.DPl, P.q);
+    for (int ip = 0; ip < P.Lp; ip++) {
+        const double cd = cos(PI * (nu - P.nu_p[ip]) / P.dnup[ip]);
+        const double cd2 = cd * cd;
+        s += (double)P.Lg * (cd2 / (cd2 + (fr / P.dnup[ip]) * cu2));
+    }
     return s;
 }
 
@@ -336,8 +346,15 @@ __global__ void __launch_bounds__(WG) k_zeta(const Prep *preps, const double *fl
             if (v > best) best = v;
         }
     }
+    // one atomic per workgroup (atomics on one address serialise in L2)
+    __shared__ double s_best[WG / 64];
     for (int off = 32; off >= 1; off >>= 1) best = fmax(best, __shfl_down(best, off, 64));
-    if ((tid & 63) == 0 && best > 0) atomicMax(&norm_bits[b], (unsigned long long)__double_as_longlong(best));  // positive doubles order as integers
+    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < WG / 64; w++) best = fmax(best, s_best[w]);
+        if (best > 0) atomicMax(&norm_bits[b], (unsigned long long)__double_as_longlong(best));  // positive doubles order as integers
+    }
 }
 
 // One workgroup per vector: the table rows (l=0 list, mixed modes, l=2, l=3 lists) written into the likelihood kernel's input block,
@@ -703,7 +720,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     HIPCHK(c, hipMemsetAsync(d_norm, 0, (size_t)B * (sizeof(unsigned long long) + 2 * sizeof(int)), st));
     hipLaunchKernelGGL(k_armm_scan, dim3(MAXP, B), dim3(64), 0, st, d_prep, d_sols, d_nsol);
     hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_rows, d_sols, d_nsol, d_fl1);
-    const int chunks = 64;
+    const int chunks = 24;
     hipLaunchKernelGGL(k_zeta, dim3(chunks, B), dim3(WG), 0, st, d_prep, d_fl1, d_nsol, d_ksi, d_norm, chunks);
     hipLaunchKernelGGL(k_rgb_rows, dim3(B), dim3(WG), 0, st, d_prep, d_rows, (const mt::PolyTab *)c->d_poly.p, d_fl1, d_nsol, d_ksi, d_norm, hx[0],
                        hx[Nx - 1], (long)Nx, step, per, (tamcmc_multiplet *)(c->d_stage.p + L.off_mults), (int *)(c->d_stage.p + L.off_pairs), d_status);
