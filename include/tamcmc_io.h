@@ -53,6 +53,12 @@ int tamcmc_io_load_model_local(const char *model_path, int slice_ind, double res
  * model_MS_Global_a1etaa3_HarveyLike_Classic (id 3).  Replaces read_MCMC_file_MS_Global + build_init_MS_Global +
  * set_noise_params (tamcmc/sources/io_ms_global.cpp:27-360, :362-1445, :1447-1536, :1718-1850); prior_class 2. */
 int tamcmc_io_load_model_global(const char *model_path, double resol, tamcmc_inputs **out);
+/* `.model` of a red-giant fit: model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (id 25) and model_RGB_asympt_aj_CteWidth_HarveyLike_v4
+ * (id 27).  Same file layout as the global fits, with the nodes of the frequency-bias spline in the "hyper priors" section and the
+ * mixed-mode keywords (delta01, DP1, alpha_g, q, Wfactor, Hfactor, rot_env, rot_core, ...) among the common parameters.  Replaces
+ * build_init_asymptotic + settings_aj_splittings_RGB (tamcmc/sources/io_asymptotic.cpp:32-955) and set_width_App2016_params_v2
+ * (io_ms_global.cpp:1625-1720); prior_class 4. */
+int tamcmc_io_load_model_asymptotic(const char *model_path, double resol, tamcmc_inputs **out);
 void tamcmc_inputs_free(tamcmc_inputs *in);
 
 int tamcmc_inputs_nparams(const tamcmc_inputs *in);

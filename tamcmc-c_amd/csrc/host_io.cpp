@@ -1,6 +1,7 @@
 // host_io.cpp -- input front end (include/tamcmc_io.h): `.data` reader, `.model` reader and the parameter-vector /
-// prior-table builders of the local fit (model_MS_local_basic) and of the global main-sequence fits
-// (model_MS_Global_aj_HarveyLike, model_MS_Global_a1etaa3_HarveyLike_Classic).  Plain C++ (no device code).
+// prior-table builders of the local fit (model_MS_local_basic), of the global main-sequence fits
+// (model_MS_Global_aj_HarveyLike, model_MS_Global_a1etaa3_HarveyLike_Classic) and of the red-giant fits
+// (model_RGB_asympt_aj_AppWidth_HarveyLike_v4, ..._CteWidth_..., io_asymptotic.cpp).  Plain C++ (no device code).
 //
 // Restates, in its own structure (a table of parameter blocks instead of the reference's per-degree vectors):
 //   Config::read_data_ascii_Ncols  tamcmc/sources/config.cpp:907-1060     Config::setup range cut  config.cpp:312-347
@@ -125,8 +126,10 @@ struct ModeLine { int l; double f; int rf, rH, rW; };
 struct Common { std::string name, prior; std::vector<double> v; };
 struct ModelFile {
     std::string id;
-    double dnu = 0, c_l = 0, numax = -9999;
+    double dnu = 0, c_l = 0, numax = -9999, err_numax = -9999;
     double range[2] = {0, 0};
+    std::vector<std::vector<double>> hyper;     // "hyper priors" rows: value, then the numbers after the prior keyword
+    std::vector<std::string> hyper_names;       // prior keyword of each row (absent in the one-column form)
     bool have_range = false;
     std::vector<ModeLine> modes;
     std::vector<std::vector<double>> eigen;     // l, nu, nu_min, nu_max, Gamma, H
@@ -175,8 +178,10 @@ int read_model_file(const char *path, int slice_ind /* < 0: global fit, one rang
             double v = 0;
             if (w.size() < 2 || !to_double(w[1], &v)) return fail(TAMCMC_IO_ERR_SYNTAX, "'!' line without a value: " + ln);
             if (c1 == '!') mf.c_l = v;
-            else if (c1 == 'n') mf.numax = v;
-            else mf.dnu = v;
+            else if (c1 == 'n') {
+                mf.numax = v;
+                if (w.size() == 3 && !to_double(w[2], &mf.err_numax)) return fail(TAMCMC_IO_ERR_SYNTAX, "'!n' line: bad uncertainty: " + ln);
+            } else mf.dnu = v;
         } else if (c0 == '*') {
             const auto w = split(ln, " \t");
             if (slice_ind < 0 && ranges > 0) return fail(TAMCMC_IO_ERR_SYNTAX, "a global fit takes ONE '*' frequency range (io_ms_global.cpp:93-104)");
@@ -202,10 +207,24 @@ int read_model_file(const char *path, int slice_ind /* < 0: global fit, one rang
     }
     if (!mf.have_range) return fail(TAMCMC_IO_ERR_SYNTAX, "no '*' frequency range for this slice index");
     if (have()) ip++;  // the reference reads one more line here and drops it (the "# Extra parameters" header, :124 then :143)
-    // --- "hyper priors" (:139-176): numeric lines up to the next '#' line; never used by the local models -> skipped
+    // --- "hyper priors" (io_ms_global.cpp:160-207): lines up to the next '#' line: value [prior keyword, its numbers]; only the
+    //     red-giant dialect (io_asymptotic.cpp) uses them (nodes of the frequency-bias spline)
     while (hashes < 4 && have()) {
         const std::string &ln = L[ip++];
-        if (!ln.empty() && ln[0] == '#') hashes++;
+        if (ln.empty()) continue;
+        if (ln[0] == '#') { hashes++; continue; }
+        const auto w = split(ln, " \t");
+        std::vector<double> r;
+        double v = 0;
+        if (w.empty() || !to_double(w[0], &v)) continue;  // free text between the section headers of a file without hyper priors
+        if (w.size() == 2) return fail(TAMCMC_IO_ERR_SYNTAX, "hyper prior: one column (value) or at least three (value, prior, numbers): " + ln);
+        r.push_back(v);
+        for (size_t k = 2; k < w.size(); k++) {
+            if (!to_double(w[k], &v)) return fail(TAMCMC_IO_ERR_SYNTAX, "hyper prior: not a number: " + ln);
+            r.push_back(v);
+        }
+        mf.hyper.push_back(r);
+        if (w.size() > 1) mf.hyper_names.push_back(w[1]);
     }
     // --- eigen table (:182-203): rows of six numbers up to the next '#' line
     while (hashes < 5 && have()) {
@@ -449,6 +468,35 @@ int build_local(const ModelFile &mf, double resol, tamcmc_inputs &out) {
     return TAMCMC_IO_OK;
 }
 
+// set_noise_params (io_ms_global.cpp:1447-1536): first two Harvey profiles fixed, the third and the white noise Gaussian
+void fill_noise_global(const ModelFile &mf, Block &noise) {
+    static const char *nn[3] = {"Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p"};
+    for (int k = 0; k < 9; k++) noise.names[(size_t)k] = nn[k % 3];
+    noise.names[9] = "White_Noise_N0";
+    for (int k = 0; k < 10; k++) {
+        noise.inputs[(size_t)k] = mf.noise[(size_t)k];
+        const bool free_k = k >= 6;
+        noise.prior_names[(size_t)k] = free_k ? "Gaussian" : "Fix";
+        noise.relax[(size_t)k] = free_k ? 1 : 0;
+    }
+    for (int g3 = 0; g3 < 3; g3++) {  // an absent / non-positive profile is switched off: (0, 0, 1) fixed
+        const int b = 3 * g3;
+        if (noise.inputs[(size_t)b] <= 0 || noise.inputs[(size_t)b + 1] <= 0 || noise.inputs[(size_t)b + 2] <= 0) {
+            for (int k = 0; k < 3; k++) { noise.prior_names[(size_t)(b + k)] = "Fix"; noise.relax[(size_t)(b + k)] = 0; }
+            noise.inputs[(size_t)b] = 0; noise.inputs[(size_t)b + 1] = 0; noise.inputs[(size_t)b + 2] = 1;
+        }
+    }
+    const auto &S = mf.noise_s2;
+    for (int k = 6; k <= 9; k++) noise.pr(0, k) = S[(size_t)k][0];
+    noise.pr(1, 6) = (S[6][1] + S[6][2]) * 3. / 2;
+    noise.pr(1, 7) = (S[7][1] + S[7][2]) * 3. / 2;
+    noise.pr(1, 8) = (S[8][1] != 0) ? (S[8][1] + S[8][2]) * 3. / 2 : noise.pr(0, 8) * 0.1;
+    noise.pr(1, 9) = noise.pr(0, 9) * 0.1;  // Gaussian white-noise prior
+    const double floor_rel[4] = {0.05, 0.005, 0.05, 0.0005};
+    for (int k = 6; k <= 9; k++)
+        if (noise.pr(1, k) / noise.pr(0, k) <= floor_rel[k - 6] && noise.prior_names[(size_t)k] != "Fix") noise.pr(1, k) = noise.pr(0, k) * floor_rel[k - 6];
+}
+
 // build_init_MS_Global (io_ms_global.cpp:362-1445) for model_MS_Global_aj_HarveyLike and
 // model_MS_Global_a1etaa3_HarveyLike_Classic, + set_noise_params (:1447-1536)
 int build_global(const ModelFile &mf, double resol, tamcmc_inputs &out) {
@@ -577,34 +625,7 @@ int build_global(const ModelFile &mf, double resol, tamcmc_inputs &out) {
         inc.fill("Empty", "Fix", 0, inc.prior_col(0), 0, 1);
         snlm.fill("Empty", "Fix", 0, snlm.prior_col(0), 0, 1);
     }
-    // ---- noise (set_noise_params, :1447-1536): first two Harvey profiles fixed, the third and the white noise Gaussian
-    {
-        static const char *nn[3] = {"Harvey-Noise_H", "Harvey-Noise_tc", "Harvey-Noise_p"};
-        for (int k = 0; k < 9; k++) noise.names[(size_t)k] = nn[k % 3];
-        noise.names[9] = "White_Noise_N0";
-        for (int k = 0; k < 10; k++) {
-            noise.inputs[(size_t)k] = mf.noise[(size_t)k];
-            const bool free_k = k >= 6;
-            noise.prior_names[(size_t)k] = free_k ? "Gaussian" : "Fix";
-            noise.relax[(size_t)k] = free_k ? 1 : 0;
-        }
-        for (int g3 = 0; g3 < 3; g3++) {  // an absent / non-positive profile is switched off: (0, 0, 1) fixed
-            const int b = 3 * g3;
-            if (noise.inputs[(size_t)b] <= 0 || noise.inputs[(size_t)b + 1] <= 0 || noise.inputs[(size_t)b + 2] <= 0) {
-                for (int k = 0; k < 3; k++) { noise.prior_names[(size_t)(b + k)] = "Fix"; noise.relax[(size_t)(b + k)] = 0; }
-                noise.inputs[(size_t)b] = 0; noise.inputs[(size_t)b + 1] = 0; noise.inputs[(size_t)b + 2] = 1;
-            }
-        }
-        const auto &S = mf.noise_s2;
-        for (int k = 6; k <= 9; k++) noise.pr(0, k) = S[(size_t)k][0];
-        noise.pr(1, 6) = (S[6][1] + S[6][2]) * 3. / 2;
-        noise.pr(1, 7) = (S[7][1] + S[7][2]) * 3. / 2;
-        noise.pr(1, 8) = (S[8][1] != 0) ? (S[8][1] + S[8][2]) * 3. / 2 : noise.pr(0, 8) * 0.1;
-        noise.pr(1, 9) = noise.pr(0, 9) * 0.1;  // Gaussian white-noise prior
-        const double floor_rel[4] = {0.05, 0.005, 0.05, 0.0005};
-        for (int k = 6; k <= 9; k++)
-            if (noise.pr(1, k) / noise.pr(0, k) <= floor_rel[k - 6] && noise.prior_names[(size_t)k] != "Fix") noise.pr(1, k) = noise.pr(0, k) * floor_rel[k - 6];
-    }
+    fill_noise_global(mf, noise);
     // ---- assemble (:1327-1376): heights, visibilities, frequencies, splitting block, widths, noise, inclination, trunc_c, do_amp
     int *pl = out.plength;
     pl[0] = Nh; pl[1] = lmax; pl[2] = Nf[0]; pl[3] = Nf[1]; pl[4] = Nf[2]; pl[5] = Nf[3];
@@ -637,6 +658,241 @@ int build_global(const ModelFile &mf, double resol, tamcmc_inputs &out) {
     out.dnu = mf.dnu; out.c_l = mf.c_l;
     out.model_id = aj ? TAMCMC_MODEL_MS_GLOBAL_AJ : TAMCMC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC;
     out.prior_class = 2;  // io_MS_Global, Config/default/priors_ctrl.list
+    out.model_name = model;
+    for (int i = 0; i < N; i++)
+        if (prior_id(A.prior_names[(size_t)i]) < 0) return fail(TAMCMC_IO_ERR_SYNTAX, "unknown prior keyword: " + A.prior_names[(size_t)i]);
+    return TAMCMC_IO_OK;
+}
+
+// build_init_asymptotic (io_asymptotic.cpp:32-838, settings_aj_splittings_RGB :841-955) for the red-giant models
+// model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (id 25) and model_RGB_asympt_aj_CteWidth_HarveyLike_v4 (id 27); width-law start values
+// and priors: set_width_App2016_params_v2 (io_ms_global.cpp:1625-1720).  The l=1 modes are not listed: the mode list carries ONE
+// l=1 placeholder line, whose slot becomes the block [delta01, DP1, alpha_g, q, sigma_Hl1, -, Wfactor, Hfactor, fref.., ferr..].
+int build_asymptotic(const ModelFile &mf, double resol, tamcmc_inputs &out) {
+    const long double pi = 3.141592653589793238L;
+    const double Hmin = 1, Hmax = 10000;
+    std::string model;
+    int do_amp = 0;
+    for (const auto &c : mf.common) {
+        if (c.name == "model_fullname") model = c.prior;
+        if (c.name == "fit_squareAmplitude_instead_Height") {
+            if (c.prior != "bool") return fail(TAMCMC_IO_ERR_SYNTAX, "fit_squareAmplitude_instead_Height must be 'bool'");
+            do_amp = c.v[0] != 0;
+        }
+    }
+    if (model.empty()) return fail(TAMCMC_IO_ERR_SYNTAX, "the .model file has no model_fullname");
+    const bool app = (model == "model_RGB_asympt_aj_AppWidth_HarveyLike_v4"), cte = (model == "model_RGB_asympt_aj_CteWidth_HarveyLike_v4");
+    if (!app && !cte) return fail(TAMCMC_IO_ERR_UNSUPPORTED, "model not covered by this loader: " + model);
+    double numax = mf.numax, err_numax = mf.err_numax;
+    if (app && numax <= 0) return fail(TAMCMC_IO_ERR_SYNTAX, "the AppWidth model needs a positive numax ('!n' line; :100-109)");
+    if (cte && numax != -9999 && numax <= 0) return fail(TAMCMC_IO_ERR_SYNTAX, "numax, when given, must be positive (:113-121)");
+    if (numax > 0 && err_numax <= 0) err_numax = 0.05 * numax;  // :397-401
+    int lmax = 0;
+    for (const auto &m : mf.modes) lmax = m.l > lmax ? m.l : lmax;
+    if (lmax > 3) return fail(TAMCMC_IO_ERR_SYNTAX, "degrees above 3 are not supported");
+    // ---- eigen table by degree (:146-197): frequencies of every degree, heights and widths of l=0
+    std::vector<double> f, fmin, fmax, h, w;
+    std::vector<int> rf, rh, rw;
+    int Nf[4] = {0, 0, 0, 0};
+    for (int el = 0; el <= lmax; el++)
+        for (const auto &e : mf.eigen) {
+            if ((int)e[0] != el) continue;
+            int match = -1, nmatch = 0;
+            for (size_t k = 0; k < mf.modes.size(); k++)
+                if (mf.modes[k].l == el && mf.modes[k].f > e[1] - 1e-2 && mf.modes[k].f < e[1] + 1e-2) { match = (int)k; nmatch++; }
+            if (nmatch != 1) return fail(TAMCMC_IO_ERR_SYNTAX, "eigen-table frequency without a unique entry in the mode list");
+            f.push_back(e[1]); fmin.push_back(e[2]); fmax.push_back(e[3]);
+            rf.push_back(mf.modes[(size_t)match].rf);
+            if (el == 0) {
+                w.push_back(e[4]); h.push_back(e[5]);
+                rw.push_back(mf.modes[(size_t)match].rW); rh.push_back(mf.modes[(size_t)match].rH);
+            }
+            Nf[el]++;
+        }
+    const int Nh = (int)h.size();
+    if (Nh < 2) return fail(TAMCMC_IO_ERR_EMPTY_RANGE, "the red-giant models need at least two l=0 modes in the eigen table");
+    // the slot of the l=1 block is opened when the walk over the listed frequencies meets the first l=1 entry (:327-339): without
+    // one, the reference writes the l=2 frequencies over the block
+    if (Nf[1] < 1) return fail(TAMCMC_IO_ERR_SYNTAX, "the mode list needs one l=1 placeholder line (its slot holds the mixed-mode parameters)");
+    if (do_amp)
+        for (int i = 0; i < Nh; i++) h[(size_t)i] = (double)(pi * w[(size_t)i] * h[(size_t)i]);
+    const std::string hname = do_amp ? "Amplitude_l0_rgb" : "Height_l0_rgb";
+    // ---- nodes of the bias spline (:251-283)
+    const int Nferr = (int)mf.hyper.size();
+    if (Nferr < 1) return fail(TAMCMC_IO_ERR_SYNTAX, "no hyper-prior rows: the v4 red-giant models take the nodes of the frequency-bias spline there");
+    const size_t hcols = mf.hyper[0].size();
+    if (hcols > 1 && (int)mf.hyper_names.size() != Nferr) return fail(TAMCMC_IO_ERR_SYNTAX, "hyper priors: every row needs a prior keyword");
+    int Nfix = 0;
+    for (int i = 0; i + 1 < Nferr; i++) {
+        if (mf.hyper[(size_t)i + 1].size() != hcols) return fail(TAMCMC_IO_ERR_SYNTAX, "hyper priors: rows of different lengths");
+        if (mf.hyper[(size_t)i + 1][0] < mf.hyper[(size_t)i][0]) return fail(TAMCMC_IO_ERR_SYNTAX, "hyper priors: the node frequencies must increase");
+        if (hcols > 1 && mf.hyper_names[(size_t)i] == "Fix") Nfix++;
+    }
+    const int nnames = (int)mf.hyper_names.size();
+    if (Nfix != nnames - 1 && Nfix != 0) return fail(TAMCMC_IO_ERR_SYNTAX, "hyper priors: either all 'Fix' or none (:262-266)");
+    std::vector<double> fref((size_t)Nferr), ferr((size_t)Nferr, 0.0);
+    for (int i = 0; i < Nferr; i++) {
+        fref[(size_t)i] = mf.hyper[(size_t)i][0];
+        if (hcols > 1) ferr[(size_t)i] = mf.hyper[(size_t)i][1];
+    }
+    const int Nmixed = 7 + 2 * Nferr + 1;
+    Block height, width, freq, snlm, vis, inc, noise;
+    height.init(Nh); vis.init(lmax); inc.init(1); noise.init(10); snlm.init(10);
+    width.init(app ? 6 : 1);
+    freq.init(Nf[0] + Nmixed + Nf[2] + Nf[3]);
+    for (int i = 0; i < Nh; i++) height.fill(hname, rh[(size_t)i] ? "Jeffreys" : "Fix", h[(size_t)i], {Hmin, Hmax, -9999., -9999.}, i, 0);
+    // l=0, then (after the block) l=2 and l=3 frequencies (:321-340)
+    auto put_freqs = [&](const std::string &name, const std::string &prior, double s1, double s2) {
+        int cpt = 0;
+        for (int i = 0; i < (int)f.size(); i++) {
+            if (i < Nf[0] || i >= Nf[0] + Nf[1]) {
+                freq.fill(name, rf[(size_t)i] ? prior : "Fix", f[(size_t)i], {fmin[(size_t)i], fmax[(size_t)i], s1, s2}, cpt, 0);
+                cpt++;
+            } else if (i == Nf[0]) cpt += Nmixed;
+        }
+    };
+    put_freqs("Frequency_RGB_l", "GUG", 0.0025 * mf.dnu, 0.0025 * mf.dnu);
+    {   // spline nodes: fixed frequencies, free (or as the file says) bias values (:343-378)
+        int cpt = Nf[0] + 7 + 1;
+        for (int i = 0; i < Nferr; i++) freq.fill("fref_bias", "Fix", fref[(size_t)i], {}, cpt++, 0);
+        if (hcols == 1) {
+            for (int i = 0; i < Nferr; i++) {
+                const double lo = (i == 0) ? -mf.dnu / 2 : -mf.dnu / 20, hi = (i == Nferr - 1 && Nferr > 1) ? mf.dnu / 2 : mf.dnu / 20;
+                freq.fill("ferr_bias", "Uniform", ferr[(size_t)i], {lo, hi, -9999., -9999.}, cpt++, 0);
+            }
+        } else {
+            for (int i = 0; i < Nferr; i++) {
+                std::vector<double> v(4, -9999.);
+                for (size_t k = 0; k + 2 < hcols && k < 4; k++) v[k] = mf.hyper[(size_t)i][2 + k];
+                freq.fill("ferr_bias", mf.hyper_names[(size_t)i], ferr[(size_t)i], v, cpt++, 0);
+            }
+        }
+    }
+    double extra[10] = {1, 2., 0.2, 0, 3, 0, 0, 0, 0, 0};  // :413-424: smoothness on, 2 muHz, |a3/a1| <= 0.2, no height normalisation, v4 priors
+    double trunc_c = -1, model_type = -1, bias_type = -1;
+    int aj_count = 0;
+    auto no_auto = [&](const Common &c) { return c.prior == "Fix_Auto" ? fail(TAMCMC_IO_ERR_SYNTAX, c.name + " cannot be Fix_Auto") : 0; };
+    auto fixed_only = [&](const Common &c) { return c.prior != "Fix" ? fail(TAMCMC_IO_ERR_SYNTAX, c.name + " must be 'Fix <value>'") : 0; };
+    static const struct { const char *a, *b, *c; int pos; } rot[8] = {
+        {"rot_env", "Rot_env", "a1_env", 0}, {"rot_core", "Rot_core", "a1_core", 1}, {"a2_core", "", "", 2}, {"a2_env", "", "", 3},
+        {"a3_env", "", "", 4}, {"a4_env", "", "", 5}, {"a5_env", "", "", 6}, {"a6_env", "", "", 7}};  // slots as the reference fills them (:846-925)
+    for (const auto &c : mf.common) {
+        const std::string &n = c.name;
+        if (n == "freq_smoothness" || n == "Freq_smoothness") {
+            if (c.prior != "bool") return fail(TAMCMC_IO_ERR_SYNTAX, "freq_smoothness must be 'bool'");
+            extra[0] = c.v[0];
+            extra[1] = c.v[1];
+        } else if (n == "trunc_c") {
+            if (int rc = fixed_only(c)) return rc;
+            trunc_c = c.v[0];
+        } else if (n == "model_type") {
+            if (int rc = fixed_only(c)) return rc;
+            model_type = c.v[0];
+        } else if (n == "bias_type") {
+            if (int rc = fixed_only(c)) return rc;
+            bias_type = (Nfix != nnames - 1) ? c.v[0] : 0;  // all nodes fixed: no bias (:462-468)
+        } else if (n == "Frequency" || n == "frequency") {
+            if (c.prior != "GUG" && c.prior != "Uniform") return fail(TAMCMC_IO_ERR_SYNTAX, "Frequency prior must be GUG or Uniform");
+            put_freqs("Frequency_l", c.prior, c.prior == "GUG" ? c.v[3] : -9999., c.prior == "GUG" ? c.v[4] : -9999.);
+        } else if (n == "delta01") {
+            if (c.prior == "Fix_Auto") freq.fill("delta01", "Uniform", 0.5 * mf.dnu / 100, {-mf.dnu / 100, mf.dnu / 100, -9999., -9999.}, Nf[0], 0);
+            else freq.fill("delta01", c.prior, c.v[0], c.v, Nf[0], 1);
+        } else if (n == "DP1" || n == "alpha_g" || n == "q" || n == "sigma_Hl1" || n == "Wfactor" || n == "Hfactor") {
+            if (int rc = no_auto(c)) return rc;
+            const int off = n == "DP1" ? 1 : n == "alpha_g" ? 2 : n == "q" ? 3 : n == "sigma_Hl1" ? 4 : n == "Wfactor" ? 6 : 7;
+            freq.fill(n, c.prior, c.v[0], c.v, Nf[0] + off, 1);
+        } else if (n == "height" || n == "Height" || n == "amplitude" || n == "Amplitude") {
+            if (int rc = no_auto(c)) return rc;
+            for (int i = 0; i < Nh; i++) height.fill(hname, rh[(size_t)i] ? c.prior : "Fix", h[(size_t)i], c.v, i, 0);
+        } else if ((n == "width" || n == "Width") && cte) {  // one width: the mean of the listed l=0 widths (:633-648)
+            if (c.prior != "Fix_Auto") return fail(TAMCMC_IO_ERR_SYNTAX, "the CteWidth model takes 'Width Fix_Auto'");
+            double mean = 0;
+            for (int i = 0; i < Nh; i++) mean = mean + w[(size_t)i] / Nh;
+            width.fill("Width_l", "Jeffreys", mean, {resol, mf.dnu / 3., -9999., -9999.}, 0, 0);
+        } else if (n == "asymetry" || n == "Asymetry") {
+            if (int rc = no_auto(c)) return rc;
+            snlm.fill("Lorentzian_asymetry", c.prior, c.v[0], c.v, 9, 1);
+        } else if (n == "visibility_l1" || n == "Visibility_l1" || n == "visibility_l2" || n == "Visibility_l2" || n == "visibility_l3" ||
+                   n == "Visibility_l3") {
+            if (int rc = no_auto(c)) return rc;
+            const int k = n.back() - '0';
+            if (lmax >= k) vis.fill(std::string("Visibility_l") + n.back(), c.prior, c.v[0], c.v, k - 1, 1);
+        } else if (n == "inclination" || n == "Inclination") {
+            if (int rc = no_auto(c)) return rc;
+            inc.fill("Inclination", c.prior, c.v[0] >= 90 ? 89.99999 : c.v[0], c.v, 0, 1);
+        } else if (n == "asphericity_eta" || n == "Asphericity_eta") {
+            snlm.names[8] = "eta0_switch"; snlm.prior_names[8] = "Fix"; snlm.relax[8] = 0; snlm.inputs[8] = 0;
+        } else if (n == "eta0_switch") {
+            if (int rc = fixed_only(c)) return rc;
+            snlm.fill("eta0_switch", "Fix", c.v[0], c.v, 8, 1);
+        } else {
+            for (const auto &r : rot)
+                if (n == r.a || n == r.b || n == r.c) {
+                    if (int rc = no_auto(c)) return rc;
+                    snlm.fill(r.a, c.prior, c.v[0], c.v, r.pos, 1);
+                    aj_count++;
+                }
+        }
+    }
+    if (aj_count != 8) return fail(TAMCMC_IO_ERR_SYNTAX, "the red-giant models need the 8 keywords rot_env, rot_core, a2_core, a2_env, a3_env ... a6_env (:712-718)");
+    if ((model_type == -1) != (bias_type == -1)) return fail(TAMCMC_IO_ERR_SYNTAX, "model_type and bias_type must both be given (:744-748)");
+    if (model_type == -1) return fail(TAMCMC_IO_ERR_SYNTAX, "the v4 red-giant models read model_type, bias_type and the node count from the vector: both keywords are needed");
+    if (cte && width.names[0] == "Empty") return fail(TAMCMC_IO_ERR_SYNTAX, "the CteWidth model needs the keyword 'Width Fix_Auto'");
+    if (app) {  // set_width_App2016_params_v2, io_ms_global.cpp:1625-1720
+        double o[6];
+        o[0] = std::fabs(numax); o[1] = std::fabs(numax);
+        o[2] = std::fabs(4. / 2150. * numax + (1. - 1000. * 4. / 2150.));
+        o[3] = std::fabs(0.8 / 2150. * numax + (4.5 - 1000. * 0.8 / 2150.));
+        o[4] = std::fabs(3400. / 2150. * numax + (1000. - 1000. * 3400. / 2150.));
+        o[5] = std::fabs(2.8 / 2200. * numax + (1. - 2.8 / 2200. * 1.));
+        if (numax < 800) o[3] = o[3] / 5;
+        width.fill("width:Appourchaux_v2:numax", "Gaussian", o[0], {o[0], err_numax, -9999., -9999.}, 0, 0);
+        width.fill("width:Appourchaux_v2:nudip", "Gaussian", o[1], {o[1], err_numax, -9999., -9999.}, 1, 0);
+        width.fill("width:Appourchaux_v2:alpha", "Uniform", o[2], {0., 6., -9999., -9999.}, 2, 0);
+        width.fill("width:Appourchaux_v2:Gamma_alpha", "Uniform", o[3], {0., 10., -9999., -9999.}, 3, 0);
+        width.fill("width:Appourchaux_v2:Wdip", "Gaussian", o[4], {o[4], o[4] * 0.25, -9999., -9999.}, 4, 0);
+        width.fill("width:Appourchaux_v2:DeltaGammadip", "Uniform", o[5], {0., 15., -9999., -9999.}, 5, 0);
+    }
+    fill_noise_global(mf, noise);
+    // ---- assemble (:724-822)
+    int *pl = out.plength;
+    pl[0] = Nh; pl[1] = lmax; pl[2] = Nf[0]; pl[3] = Nmixed; pl[4] = Nf[2]; pl[5] = Nf[3];
+    pl[6] = snlm.n; pl[7] = width.n; pl[8] = 10; pl[9] = 1; pl[10] = 6;
+    int N = 0;
+    for (int k = 0; k < 11; k++) N += pl[k];
+    Block &A = out.all;
+    A.init(N);
+    auto put = [&](Block &b, int pos) {
+        for (int i = 0; i < b.n; i++) {
+            A.names[(size_t)(pos + i)] = b.names[(size_t)i];
+            A.prior_names[(size_t)(pos + i)] = b.prior_names[(size_t)i];
+            A.inputs[(size_t)(pos + i)] = b.inputs[(size_t)i];
+            A.relax[(size_t)(pos + i)] = b.relax[(size_t)i];
+            for (int k = 0; k < 4; k++) A.pr(k, pos + i) = b.pr(k, i);
+        }
+    };
+    int p0 = 0;
+    put(height, p0); p0 += pl[0];
+    put(vis, p0); p0 += pl[1];
+    put(freq, p0); p0 += pl[2] + pl[3] + pl[4] + pl[5];
+    put(snlm, p0); p0 += pl[6];
+    put(width, p0); p0 += pl[7];
+    put(noise, p0); p0 += pl[8];
+    put(inc, p0); p0 += pl[9];
+    A.fill("Truncation parameter", "Fix", trunc_c > 0 ? trunc_c : 10000., {}, p0, 1);
+    A.fill("Switch for fit of Amplitudes or Heights", "Fix", (double)do_amp, {}, p0 + 1, 1);
+    A.fill("Maximum limit on random values generated by N(0,sigma_m)", "Fix", mf.dnu / 10., {}, p0 + 2, 1);
+    A.fill("model type ", "Fix", model_type, {}, p0 + 3, 1);
+    A.fill("bias type ", "Fix", bias_type, {}, p0 + 4, 1);
+    A.fill("Nferr ", "Fix", (double)Nferr, {}, p0 + 5, 1);
+    if (bias_type == 0 && Nfix != nnames - 1)  // no bias asked for: the node values are pinned to 0 (:825-833)
+        for (int i = 0; i < N; i++)
+            if (A.names[(size_t)i] == "ferr_bias") A.fill("ferr_bias", "Fix", 0, {}, i, 1);
+    for (int k = 0; k < 10; k++) out.extra[k] = extra[k];
+    out.range[0] = mf.range[0]; out.range[1] = mf.range[1];
+    out.dnu = mf.dnu; out.c_l = mf.c_l;
+    out.model_id = app ? 25 : 27;  // TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 / _CTEWIDTH_V4
+    out.prior_class = 4;           // io_asymptotic, Config/default/priors_ctrl.list
     out.model_name = model;
     for (int i = 0; i < N; i++)
         if (prior_id(A.prior_names[(size_t)i]) < 0) return fail(TAMCMC_IO_ERR_SYNTAX, "unknown prior keyword: " + A.prior_names[(size_t)i]);
@@ -718,6 +974,18 @@ int tamcmc_io_load_model_global(const char *model_path, double resol, tamcmc_inp
     if (rc) return rc;
     tamcmc_inputs *in = new tamcmc_inputs();
     rc = build_global(mf, resol, *in);
+    if (rc) { delete in; return rc; }
+    *out = in;
+    return TAMCMC_IO_OK;
+}
+
+int tamcmc_io_load_model_asymptotic(const char *model_path, double resol, tamcmc_inputs **out) {
+    if (!model_path || !out) return fail(TAMCMC_IO_ERR_ARG, "bad argument");
+    ModelFile mf;
+    int rc = read_model_file(model_path, -1, mf);
+    if (rc) return rc;
+    tamcmc_inputs *in = new tamcmc_inputs();
+    rc = build_asymptotic(mf, resol, *in);
     if (rc) { delete in; return rc; }
     *out = in;
     return TAMCMC_IO_OK;

@@ -17,6 +17,7 @@ EXTRA_ABI += [
     ("tamcmc_io_select_range", C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, _i64p, _i64p]),
     ("tamcmc_io_load_model_local", C.c_int, [C.c_char_p, C.c_int, C.c_double, C.POINTER(_vp)]),
     ("tamcmc_io_load_model_global", C.c_int, [C.c_char_p, C.c_double, C.POINTER(_vp)]),
+    ("tamcmc_io_load_model_asymptotic", C.c_int, [C.c_char_p, C.c_double, C.POINTER(_vp)]),
     ("tamcmc_inputs_free", None, [_vp]),
     ("tamcmc_cfg_last_error", C.c_char_p, []),
     ("tamcmc_cfg_open", C.c_int, [C.c_char_p, C.POINTER(_vp)]),
@@ -117,6 +118,15 @@ class GlobalInputs(ModelInputs):
         super().__init__(h)
 
 
+class AsymptoticInputs(ModelInputs):
+    """Red-giant fit (model_RGB_asympt_aj_AppWidth_HarveyLike_v4, model_RGB_asympt_aj_CteWidth_HarveyLike_v4; io_asymptotic.cpp)."""
+
+    def __init__(self, model_path, resol):
+        h = _vp()
+        _check(_L().tamcmc_io_load_model_asymptotic(str(model_path).encode(), float(resol), C.byref(h)), "load_model_asymptotic")
+        super().__init__(h)
+
+
 def star_from_inputs(inp, x, y=None):
     star = Star(inp.model_id, inp.params, inp.plength, x, inp.relax, inp.priors, inp.priors_switch, inp.names, inp.prior_class,
                 inp.extra_priors)
@@ -128,6 +138,14 @@ def load_global_star(model_path, data_path, x_col=0, y_col=1):
     """`.model` + `.data` of a global fit -> (Star with x, y cut to the file's range, GlobalInputs)."""
     tab = read_data(data_path)
     inp = GlobalInputs(model_path, tab[2, x_col] - tab[1, x_col])  # config.cpp:682
+    a, b = select_range(tab, inp.freq_range[0], inp.freq_range[1], x_col)
+    return star_from_inputs(inp, np.ascontiguousarray(tab[a:b, x_col]), np.ascontiguousarray(tab[a:b, y_col])), inp
+
+
+def load_asymptotic_star(model_path, data_path, x_col=0, y_col=1):
+    """`.model` + `.data` of a red-giant fit -> (Star with x, y cut to the file's range, AsymptoticInputs)."""
+    tab = read_data(data_path)
+    inp = AsymptoticInputs(model_path, tab[2, x_col] - tab[1, x_col])
     a, b = select_range(tab, inp.freq_range[0], inp.freq_range[1], x_col)
     return star_from_inputs(inp, np.ascontiguousarray(tab[a:b, x_col]), np.ascontiguousarray(tab[a:b, y_col])), inp
 

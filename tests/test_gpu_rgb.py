@@ -116,3 +116,35 @@ def test_structured_scan_finds_the_cells_of_the_dense_walk(pkg, synth, monkeypat
         assert np.array_equal(out["0"][1], out["1"][1]), c
         assert np.array_equal(out["0"][0], out["1"][0]), c
         ctx.close()
+
+
+def test_real_red_giant_from_the_reference_files(pkg, oracle):
+    """KIC 10722175 from the reference's own example files (test/inputs/RGB/v1.86.0, copied as data under tests/golden/): `.model`
+    through the red-giant dialect of the input front end, `.data` cut to its range, then the device path against the oracle at the
+    file's starting point and a short tempered run of the host-driven engine on the real spectrum."""
+    import os
+    from tamcmc_c_amd import inputs
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    star, inp = inputs.load_asymptotic_star(os.path.join(g, "RGB_10722175.model"), os.path.join(g, "RGB_10722175.data"))
+    assert inp.model_id == pkg.MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 and star.x.size == 6099
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, star.y)
+    T = 1.5 ** np.arange(4)
+    P = np.tile(star.params, (4, 1))
+    o = np.cumsum([0] + list(star.plength))
+    P[1:, o[3] + 1] += [0.05, -0.08, 0.11]           # period spacing
+    P[1:, o[3] + 24:o[4]] = 0.01 * np.random.default_rng(1).standard_normal((3, 16))   # bias values at the spline nodes
+    ref, m_o, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, star.y, 1.0, T, want_model=True)
+    got, m_d, st_d = ctx.loglike_params_batch(star.model_id, P, star.plength, T, want_model=True)
+    assert (st_o == 0).all() and (st_d == 0).all()
+    rel = np.linalg.norm(m_d - m_o, axis=1) / np.linalg.norm(m_o, axis=1)
+    assert rel.max() < 1e-7, rel
+    assert np.allclose(got, ref, rtol=1e-8, atol=0), np.abs(got / ref - 1).max()
+    s = pkg.Sampler(ctx, star, nchains=4, lambda_temp=1.5, seed=11, engine="host", Nt_learn=(20, 150), periods_learn=(1,))
+    st0 = s.state()
+    assert np.allclose(st0["logL"], ref[0] * T[0] / T, rtol=1e-8) and np.isfinite(st0["logPrior"]).all()
+    smp, stat = s.run(160, stats=True)
+    assert np.isfinite(stat).all() and (smp[:, 0] != smp[0, 0]).any() and s.state()["swap_attempts"] == 159
+    assert stat[-40:, 0, 2].mean() > st0["logPost"][0] - 40.0
+    s.close()
+    ctx.close()
