@@ -16,6 +16,7 @@ static int try_all(const std::string &path) {
     for (int slice = 0; slice < 3; slice++)
         if (tamcmc_io_load_model_local(path.c_str(), slice, 0.01, &in) == TAMCMC_IO_OK) { ok++; tamcmc_inputs_free(in); }
     if (tamcmc_io_load_model_global(path.c_str(), 0.01, &in) == TAMCMC_IO_OK) { ok++; tamcmc_inputs_free(in); }
+    if (tamcmc_io_load_model_asymptotic(path.c_str(), 0.01, &in) == TAMCMC_IO_OK) { ok++; tamcmc_inputs_free(in); }
     double *tab = nullptr;
     int64_t nr = 0, nc = 0;
     if (tamcmc_io_read_data(path.c_str(), &tab, &nr, &nc) == TAMCMC_IO_OK) {

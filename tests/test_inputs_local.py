@@ -189,7 +189,7 @@ def test_parsers_survive_malformed_input_under_sanitizers(tmp_path):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
            os.path.join(root, "tests", "parser_fuzz_driver.cpp"), os.path.join(src, "host_io.cpp"), os.path.join(src, "host_cfg.cpp")]
     subprocess.run(cmd, check=True, capture_output=True, timeout=300)
-    files = [MODEL, SUN, DATA, os.path.join(GOLD, "sampler_test.cfg"), os.path.join(GOLD, "errors_test.cfg")]
+    files = [MODEL, SUN, os.path.join(GOLD, "RGB_10722175.model"), DATA, os.path.join(GOLD, "sampler_test.cfg"), os.path.join(GOLD, "errors_test.cfg")]
     r = subprocess.run([exe, str(tmp_path / "variant.txt")] + files, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
