@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--packed-stars", type=int, default=4,
                     help="extra leg at N=1: this many independent C3 stars co-resident on the GPU (0 = skip); reported under 'packed', "
                          "never as 'value' (the headline stays one star per GPU, BASELINE configs[2])")
+    ap.add_argument("--rgb-steps", type=int, default=150,
+                    help="extra leg at N=1: BASELINE configs[4] family (red giant, model id 25, 2e5 bins, 40 chains; host-driven engine with the "
+                         "mixed-mode solver on the device), this many timed iterations (0 = skip); reported under 'c5_rgb'")
     ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
     return ap.parse_args()
 
@@ -188,6 +191,31 @@ def main():
         for ck, sk_ in pool:
             sk_.close()
             ck.close()
+
+    if a.rgb_steps > 0 and a.sampler == "mh" and world == 1:
+        # BASELINE configs[4] family: red-giant star, mixed modes solved per proposal (csrc/rgb_prestep.hip), 40 tempered chains
+        rs = synth.make_c5_star(nx=200000, nmax=10, dnu=10.0, bias_type=1, nferr=6)
+        rc = pkg.HipContext(device_index, precision=prec, timing=True)
+        rc.set_spectrum(rs.x, np.ones_like(rs.x))
+        _, mr, _ = rc.loglike_params_batch(rs.model_id, rs.params, rs.plength, want_model=True)
+        rs.set_spectrum_from_model(mr[0], 7)
+        rc.set_spectrum(rs.x, rs.y)
+        rsmp = pkg.Sampler(rc, rs, nchains=40, lambda_temp=1.15, seed=5, engine="host", Nt_learn=(10, 100), periods_learn=(1,))
+        rsmp.run(100, record=False)
+        rc.reset_kernel_stats()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rsmp.run(a.rgb_steps, record=False)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        r_ms, r_l, r_e = rc.kernel_stats()
+        extra["c5_rgb"] = {"samples_per_s": a.rgb_steps / e1, "ms_per_step": 1e3 * e1 / a.rgb_steps, "steps": a.rgb_steps,
+                           "workload": f"model_RGB_asympt_aj_AppWidth_HarveyLike_v4, Nx=200000, {rs.params.size} params ({rs.nvars} free), "
+                                       "40 tempered chains, ~150 mixed modes per chain from the device ARMM solver; host-driven engine",
+                           "k_loglike_us_per_launch": r_ms / max(r_l, 1) * 1e3,
+                           "k_loglike_alg_GBps": 16.0 * 200000 * r_e / max(r_ms * 1e-3, 1e-12) / 1e9}
+        rsmp.close()
+        rc.close()
 
     shapes = []
     if world == 1 and a.sampler == "mh":

@@ -7,6 +7,7 @@
 // gradient of the log-posterior, with the asymmetric-proposal correction in the acceptance ratio.
 #include <algorithm>
 #include <cmath>
+#include <omp.h>
 #include <cstring>
 #include <limits>
 
@@ -312,18 +313,27 @@ int MALA::step(Model_def *cur, Model_def *prop, Data *data, Config *) {
     const long i = iteration;
     gamma = c0 / (1. + i);
     int rc = TAMCMC_OK;
+    // The per-chain linear algebra (drift, proposal, the two proposal densities, adaptation + Cholesky) touches per-chain state only
+    // and its random numbers are addressed by (chain, iteration): the chains run on OpenMP threads like the reference's
+    // `#pragma omp parallel for` over m (MALA.cpp:648), with the same results for any thread count.
+    int nt = omp_get_max_threads();
+    if (nt > 16) nt = 16;
+    if (nt > Nchains) nt = (int)Nchains;
+    if (nt < 1) nt = 1;
     std::vector<std::vector<double>> drift_cur((size_t)Nchains);
     if (use_drift) {
         std::vector<char> need((size_t)Nchains);
         for (long m = 0; m < Nchains; m++) need[(size_t)m] = !grad_valid[(size_t)m];
         rc = compute_gradients(cur, data, grad_cur, need);
         if (rc) return rc;
+#pragma omp parallel for schedule(static) num_threads(nt)
         for (long m = 0; m < Nchains; m++) {
             grad_valid[(size_t)m] = 1;
             drift_cur[(size_t)m] = D_MALA(grad_cur.row(m), (int)m);
         }
     }
     // [1] propose every chain (MALA.cpp:481-487)
+#pragma omp parallel for schedule(static) num_threads(nt)
     for (long m = 0; m < Nchains; m++) {
         std::vector<double> v = new_prop_values(cur->vars.row(m), (int)m, use_drift ? drift_cur[(size_t)m].data() : nullptr);
         std::memcpy(prop->params.row(m), cur->params.row(m), (size_t)cur->get_Nparams() * sizeof(double));
@@ -342,6 +352,7 @@ int MALA::step(Model_def *cur, Model_def *prop, Data *data, Config *) {
         if (rc) return rc;
     }
     // [3] accept / reject (MALA.cpp:490-551)
+#pragma omp parallel for schedule(static) num_threads(nt)
     for (long m = 0; m < Nchains; m++) {
         double u, u_unused;
         rng_uniform2(seed, RNG_ACCEPT, (uint32_t)m, (uint64_t)i, 0, u, u_unused);
