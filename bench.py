@@ -54,8 +54,14 @@ def parse():
     ap.add_argument("--rgb-steps", type=int, default=150,
                     help="extra leg at N=1: BASELINE configs[4] family (red giant, model id 25, 2e5 bins, 40 chains; host-driven engine with the "
                          "mixed-mode solver on the device), this many timed iterations (0 = skip); reported under 'c5_rgb'")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline run (no packed / red-giant / MALA / launch-shape / CPU legs): the command profiled under "
+                         "rocprofv3 for profiles/, so that the per-kernel averages are those of the headline launches")
     ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.headline_only:
+        a.mala_steps, a.packed_stars, a.rgb_steps, a.no_cpu_baseline = 0, 0, 0, True
+    return a
 
 
 def cpu_baseline(star, y, nchains, lam, budget_s):
@@ -218,7 +224,7 @@ def main():
         rc.close()
 
     shapes = []
-    if world == 1 and a.sampler == "mh":
+    if world == 1 and a.sampler == "mh" and not a.headline_only:
         # the same kernel at other launch sizes (standalone batched calls through the C ABI, live HIP-event timing): the sampler's
         # launches above are small (one chain group), these show where the kernel goes with more evaluations per launch
         rng = np.random.default_rng(3)

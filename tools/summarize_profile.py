@@ -17,7 +17,7 @@ def newest(pattern):
 
 ks = newest(f"{src}/trace/*/*kernel_stats.csv")
 if ks:
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --mala-steps 0`", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --headline-only` (the default run without its extra legs: only the timed headline launches and their warm-up)", "",
               "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks[0])):
         lines.append(f"| `{r['Name'][:110]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.2f} | "
@@ -25,7 +25,7 @@ if ks:
     lines.append("")
 try:
     b = json.loads(open(f"{src}/bench.json").read())
-    lines += ["## bench.py line of the same build (un-profiled run)", "", "```json", json.dumps(b, indent=1), "```", ""]
+    lines += ["## `python3 bench.py` line of the same build (un-profiled default run, all legs)", "", "```json", json.dumps(b, indent=1), "```", ""]
 except Exception as e:
     lines += [f"(no bench.json: {e})", ""]
 agg = collections.defaultdict(list)
