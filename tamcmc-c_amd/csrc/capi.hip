@@ -128,7 +128,14 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     a.nnoise = (const int32_t *)(c->d_stage.p + L.off_nn);
     a.partials = c->d_part.p;
     a.model = model ? c->d_model.p : nullptr;
-    if (const char *ep = getenv("TAMCMC_PROBE_SKIP")) a.probe = atoi(ep);
+    if (const char *ep = getenv("TAMCMC_PROBE_SKIP")) {  // timing tool only (tools/phase_probe.py): say so, loudly, once
+        a.probe = atoi(ep);
+        static bool warned = false;
+        if (a.probe && !warned) {
+            warned = true;
+            fprintf(stderr, "tamcmc_hip: TAMCMC_PROBE_SKIP=%d skips kernel phases -- the log-likelihoods of this process are WRONG (timing probe only)\n", a.probe);
+        }
+    }
     if (device_tables) a.tile_rot = tile_rot;
     else {
         const int32_t *pairs = (const int32_t *)(c->h_stage.p + L.off_pairs);
