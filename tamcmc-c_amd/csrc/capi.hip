@@ -48,6 +48,7 @@ void tamcmc_hip_destroy(tamcmc_hip_ctx *c) {
     c->h_stage.release(); c->d_stage.release();
     c->d_part.release(); c->d_S.release(); c->d_model.release(); c->h_S.release();
     c->d_fd.release(); c->d_poly.release(); c->h_fd.release();
+    c->d_rgb.release(); c->h_rgb.release(); c->d_bg.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -268,6 +269,7 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, cons
     if (rc) return rc;
     rc = run_staged(c, B, StageLayout(B, stride, (size_t)B * per), stride, Tcoefs, p, logL, model, rgb, rot);
     if (rc) return rc;
+    if (rgb) tamcmc::rgb_collect_status(c, B, status, &first_err);
     for (int b = 0; b < B; b++)
         if (status[b] != TAMCMC_OK) logL[b] = NAN;
     return first_err;

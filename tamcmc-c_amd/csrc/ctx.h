@@ -75,6 +75,7 @@ struct tamcmc_hip_ctx {
     tamcmc::DevBuf<unsigned char> d_stage;
     tamcmc::DevBuf<double> d_part, d_S, d_model;
     tamcmc::DevBuf<unsigned char> d_rgb;  // red-giant pre-step workspace (rgb_prestep.hip)
+    tamcmc::PinBuf<unsigned char> h_rgb;  // its pinned host image: [Prep B | RowIn B] going up, [int status B] coming back
     tamcmc::DevBuf<double> d_bg;  // FAST far field: background series per (evaluation, tile) (bg_series.h)
     // finite-difference batches built on the device (fd_batch.hip)
     tamcmc::DevBuf<unsigned char> d_fd, d_poly;

@@ -18,6 +18,8 @@
 // pole, the interpolation extrapolates and the 0.1 % ratio test rejects it) -- tests/test_oracle_rgb.py documents it.
 #include <hip/hip_runtime.h>
 
+#include <omp.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -644,8 +646,12 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
     if (plength[2] > MAXL || plength[4] > MAXL || plength[5] > MAXL) return TAMCMC_ERR_BAD_ARG;
     std::vector<Unpacked> U((size_t)B);
-    std::vector<Prep> P((size_t)B);
-    std::vector<RowIn> R((size_t)B);
+    // Prep and RowIn arrays are filled in ONE pinned block (a single asynchronous upload); the per-vector status words come back
+    // into the same block and are read by rgb_collect_status after the caller's final synchronisation
+    const size_t bytes_prep = ((size_t)B * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)B * sizeof(RowIn) + 15) & ~(size_t)15;
+    HIPCHK(c, c->h_rgb.reserve(bytes_prep + bytes_rows + (size_t)B * sizeof(int)));
+    Prep *P = (Prep *)c->h_rgb.p;
+    RowIn *R = (RowIn *)(c->h_rgb.p + bytes_prep);
     const int per = plength[2] + plength[4] + plength[5] + CAP1;
     const StageLayout L(B, stride, (size_t)B * per);
     HIPCHK(c, c->h_stage.reserve(L.off_mults));
@@ -653,13 +659,16 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     unsigned char *h = c->h_stage.p;
     int32_t *h_nh = (int32_t *)(h + L.off_nh), *h_nn = (int32_t *)(h + L.off_nn);
     double *h_noise = (double *)(h + L.off_noise);
-    double fmin_all = 1e300;
+    int nthr = omp_get_max_threads();  // the scalar unpack of a vector (width law, fits, spline coefficients) is independent of the others
+    if (nthr > 8) nthr = 8;
+    if (nthr > B / 4) nthr = B / 4 > 0 ? B / 4 : 1;
+#pragma omp parallel for schedule(static) num_threads(nthr)
     for (int b = 0; b < B; b++) {
         const double *p = params + (size_t)b * Nparams;
         Unpacked &u = U[(size_t)b];
-        RowIn &ri = R[(size_t)b];
+        RowIn &ri = R[b];
         std::memset(&ri, 0, sizeof ri);
-        int st = unpack(p, plength, step, cte_width, u, P[(size_t)b]);
+        int st = unpack(p, plength, step, cte_width, u, P[b]);
         if (st == TAMCMC_OK && u.bias_type != 0) {
             Spline s;
             if (u.Nferr > MAXNODE || !s.set(p + u.o1 + 8, p + u.o1 + 8 + u.Nferr, u.Nferr, u.bias_type == 1 ? 1 : 2)) st = TAMCMC_ERR_BAD_ARG;
@@ -672,8 +681,8 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
             }
         }
         status[b] = st;
-        P[(size_t)b].status = st;
-        P[(size_t)b].probe_dense = dense_scan ? 1 : 0;
+        P[b].status = st;
+        P[b].probe_dense = dense_scan ? 1 : 0;
         ri.status = st;
         if (st == TAMCMC_OK) {
             ri.Nfl0 = u.Nfl0; ri.Nfl2 = u.Nfl2; ri.Nfl3 = u.Nfl3; ri.lmax = u.lmax; ri.do_amp = u.do_amp ? 1 : 0; ri.cte_width = cte_width ? 1 : 0;
@@ -689,7 +698,6 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
             ri.rot_env = u.rot_env; ri.rot_core = u.rot_core;
             ri.a2 = p[u.os + 2]; ri.a3 = p[u.os + 4]; ri.a4 = p[u.os + 5]; ri.a5 = p[u.os + 6]; ri.a6 = p[u.os + 7];
             ri.fmin = u.fmin; ri.fmax = u.fmax;
-            if (u.fmin < fmin_all) fmin_all = u.fmin;
             for (int k = 0; k < u.Nnoise; k++) h_noise[(size_t)b * stride + k] = std::fabs(p[u.onoise + k]);
             h_nh[b] = (u.Nnoise - 1) / 3; h_nn[b] = u.Nnoise;
         } else {
@@ -697,9 +705,14 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
             h_nh[b] = 0; h_nn[b] = 1;
         }
     }
+    double fmin_all = 1e300;
+    *first_err = TAMCMC_OK;
+    for (int b = 0; b < B; b++) {
+        if (status[b] == TAMCMC_OK && U[(size_t)b].fmin < fmin_all) fmin_all = U[(size_t)b].fmin;
+        if (status[b] != TAMCMC_OK && *first_err == TAMCMC_OK) *first_err = status[b];
+    }
     hipStream_t st = c->stream;
     // ---- device workspace
-    const size_t bytes_prep = ((size_t)B * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)B * sizeof(RowIn) + 15) & ~(size_t)15;
     const size_t nsolbuf = (size_t)B * MAXSOL;
     HIPCHK(c, c->d_rgb.reserve(bytes_prep + bytes_rows + nsolbuf * 3 * sizeof(double) + (size_t)B * (3 * sizeof(int) + sizeof(unsigned long long)) + 64));
     unsigned char *base = c->d_rgb.p;
@@ -715,8 +728,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
         c->poly_ready = true;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage.p, L.off_mults, hipMemcpyHostToDevice, st));  // header only
-    HIPCHK(c, hipMemcpyAsync(d_prep, P.data(), (size_t)B * sizeof(Prep), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_rows, R.data(), (size_t)B * sizeof(RowIn), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_prep, P, bytes_prep + bytes_rows, hipMemcpyHostToDevice, st));  // Prep and RowIn arrays, contiguous on both sides
     HIPCHK(c, hipMemsetAsync(d_norm, 0, (size_t)B * (sizeof(unsigned long long) + 2 * sizeof(int)), st));
     hipLaunchKernelGGL(k_armm_scan, dim3(MAXP, B), dim3(64), 0, st, d_prep, d_sols, d_nsol);
     hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_rows, d_sols, d_nsol, d_fl1);
@@ -725,20 +737,27 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     hipLaunchKernelGGL(k_rgb_rows, dim3(B), dim3(WG), 0, st, d_prep, d_rows, (const mt::PolyTab *)c->d_poly.p, d_fl1, d_nsol, d_ksi, d_norm, hx[0],
                        hx[Nx - 1], (long)Nx, step, per, (tamcmc_multiplet *)(c->d_stage.p + L.off_mults), (int *)(c->d_stage.p + L.off_pairs), d_status);
     HIPCHK(c, hipGetLastError());
-    std::vector<int> dst((size_t)B);
-    HIPCHK(c, hipMemcpyAsync(dst.data(), d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    *first_err = TAMCMC_OK;
-    for (int b = 0; b < B; b++) {
-        if (status[b] == TAMCMC_OK) status[b] = dst[(size_t)b];
-        if (status[b] != TAMCMC_OK && *first_err == TAMCMC_OK) *first_err = status[b];
-    }
+    // the device-side status words (row builder, solver overflow) travel back behind the kernels; no synchronisation here: the
+    // likelihood launch that follows runs on whatever rows were written (a failed vector has an empty range) and the caller reads
+    // the words after ITS synchronisation (rgb_collect_status)
+    HIPCHK(c, hipMemcpyAsync(c->h_rgb.p + bytes_prep + bytes_rows, d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     *per_out = per;
     *stride_out = stride;
     const int tb = tile_bins(c->wgs, c->K), ntiles = (int)((Nx + tb - 1) / tb);
     double t = (fmin_all < 1e299) ? (fmin_all - hx[0]) / (hx[1] - hx[0]) / (double)tb - 3.0 : 0.0;  // first near-field tile: a little below the lowest radial mode
     *tile_rot_out = (t > 0 && t < ntiles) ? (int)t : 0;
     return TAMCMC_OK;
+}
+
+// After the stream has been synchronised: merges the device-side status words into status[] / first_err.
+void rgb_collect_status(tamcmc_hip_ctx *c, int B, int32_t *status, int *first_err) {
+    using namespace rgb;
+    const size_t bytes_prep = ((size_t)B * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)B * sizeof(RowIn) + 15) & ~(size_t)15;
+    const int *dst = (const int *)(c->h_rgb.p + bytes_prep + bytes_rows);
+    for (int b = 0; b < B; b++) {
+        if (status[b] == TAMCMC_OK) status[b] = dst[b];
+        if (status[b] != TAMCMC_OK && *first_err == TAMCMC_OK) *first_err = status[b];
+    }
 }
 
 }  // namespace tamcmc
