@@ -1,6 +1,7 @@
 // host_model_def.cpp -- Model_def: chain-indexed container + dispatch (mirror of tamcmc/sources/model_def.cpp).
 // The per-bin work of call_model / call_likelihood goes to the device through the C ABI; there is no CPU path.
 #include <cmath>
+#include <omp.h>
 #include <limits>
 
 #include "host_sampler.h"
@@ -68,7 +69,10 @@ long double Model_def::call_prior_params(const double *p) {
     case 4: r = priors_asymptotic(p, plength, priors_params, priors_params_names_switch, extra_priors, &st); break;
     default: st = TAMCMC_ERR_BAD_MODEL; r = -std::numeric_limits<long double>::infinity(); break;
     }
-    if (st != TAMCMC_OK) last_status = st;
+    if (st != TAMCMC_OK) {
+#pragma omp atomic write
+        last_status = st;  // (chains evaluate their priors on OpenMP threads)
+    }
     return r;
 }
 
@@ -103,8 +107,12 @@ long double Model_def::generate_model(Data *data_struc, long m, const std::vecto
 
 int Model_def::generate_models_batch(Data *data_struc, const std::vector<double> &Tcoefs) {
     std::vector<int> live;
+    int nt = omp_get_max_threads();  // the priors of the chains are independent (long double, the reference's term order per chain)
+    if (nt > 8) nt = 8;
+    if (nt > Nmodels / 4) nt = Nmodels / 4 > 0 ? (int)(Nmodels / 4) : 1;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (long m = 0; m < Nmodels; m++) logPrior[(size_t)m] = (double)call_prior(data_struc, (int)m);
     for (long m = 0; m < Nmodels; m++) {
-        logPrior[(size_t)m] = (double)call_prior(data_struc, (int)m);
         if (logPrior[(size_t)m] != -INFINITY) live.push_back((int)m);
         else {
             logLikelihood[(size_t)m] = init_logLikelihood[(size_t)m];
