@@ -34,7 +34,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # vector fp64
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--chains", type=int, default=20)
     ap.add_argument("--nx", type=int, default=100000)

@@ -20,7 +20,7 @@ P = np.tile(params, (B, 1))
 o = np.cumsum([0] + list(pl))
 P[1:, o[3] + 1] *= 1 + 0.001 * rng.standard_normal(B - 1)
 T = 1.2 ** np.arange(B)
-c = pkg.HipContext(0, precision=pkg.PRECISION_FAST, timing=True)
+c = pkg.HipContext(0, precision=pkg.PRECISION_FAST, timing=True, bins_per_thread=int(os.environ["RGB_K"]) if os.environ.get("RGB_K") else None)
 c.set_spectrum(x, np.ones(Nx))
 _, m, st = c.loglike_params_batch(pkg.MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4, P[:1], pl, T[:1], want_model=True)
 assert st[0] == 0
