@@ -56,7 +56,9 @@ typedef struct tamcmc_sampler_config {
                                       (tamcmc_sampler_run_packed): the co-resident stars already fill each other's gaps */
 } tamcmc_sampler_config;
 
-/* The context must already hold the spectrum (tamcmc_hip_set_spectrum). It is borrowed, not owned. */
+/* The context must already hold the spectrum (tamcmc_hip_set_spectrum). It is borrowed, not owned: the sampler uses its stream and
+ * device buffers.  Destruction order is free: tamcmc_hip_destroy on a context that still has samplers defers the release to the
+ * last tamcmc_sampler_destroy. */
 int tamcmc_sampler_create(tamcmc_sampler **s, tamcmc_hip_ctx *ctx, const tamcmc_sampler_config *cfg);
 void tamcmc_sampler_destroy(tamcmc_sampler *s);
 int64_t tamcmc_sampler_nvars(const tamcmc_sampler *s);

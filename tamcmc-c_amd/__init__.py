@@ -9,6 +9,7 @@ The directory name contains a hyphen, so import it through `load_package()` of
 __graft_entry__.py (it registers this package as module `tamcmc_c_amd`).
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -121,6 +122,7 @@ class HipContext:
         if st != OK:
             raise TamcmcError(st, "tamcmc_hip_create failed (no GPU / HIP runtime?) -- there is no CPU fallback")
         self._h = h
+        self._samplers = weakref.WeakSet()  # samplers borrow the context: they are destroyed first, whatever order the caller (or the GC) uses
         self.Nx = 0
         self.set_option(OPT_PRECISION, precision)
         self.set_option(OPT_TIMING, 1 if timing else 0)
@@ -131,6 +133,8 @@ class HipContext:
 
     def close(self):
         if getattr(self, "_h", None):
+            for smp in list(getattr(self, "_samplers", ())):
+                smp.close()
             self._L.tamcmc_hip_destroy(self._h)
             self._h = None
 

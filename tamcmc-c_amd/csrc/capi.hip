@@ -40,8 +40,17 @@ int tamcmc_hip_create(tamcmc_hip_ctx **out, int device) {
     return TAMCMC_OK;
 }
 
+// (private, host_capi.cpp) a sampler borrows the context for its whole life
+void tamcmc_hip_ctx_attach(tamcmc_hip_ctx *c) { if (c) c->attached++; }
+void tamcmc_hip_ctx_detach(tamcmc_hip_ctx *c) {
+    if (!c) return;
+    c->attached--;
+    if (c->attached <= 0 && c->zombie) { c->zombie = false; tamcmc_hip_destroy(c); }
+}
+
 void tamcmc_hip_destroy(tamcmc_hip_ctx *c) {
     if (!c) return;
+    if (c->attached > 0) { c->zombie = true; return; }  // freed by the last sampler's destruction
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->dx.release(); c->dy.release(); c->dlogx.release();

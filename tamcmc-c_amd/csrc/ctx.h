@@ -82,6 +82,10 @@ struct tamcmc_hip_ctx {
     tamcmc::PinBuf<unsigned char> h_fd;
     bool poly_ready = false;
     tamcmc::PinBuf<double> h_S;
+    // samplers created on this context (they borrow its stream and buffers): tamcmc_hip_destroy with samplers still attached only
+    // marks the context; the last tamcmc_sampler_destroy frees it -- any destruction order is safe
+    int attached = 0;
+    bool zombie = false;
     // stats
     double kernel_ms = 0;
     int64_t launches = 0, evals = 0;

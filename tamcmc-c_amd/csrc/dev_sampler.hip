@@ -152,9 +152,13 @@ __device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const doub
         A[e] = (v + (i == j ? a.epsi2 : 0.0)) * sig;
     }
     __syncthreads();
-    // right-looking Cholesky in place (lower triangle of A): column scale + trailing update per step
+    // right-looking Cholesky in place (lower triangle of A): column scale + trailing update per step.  A matrix that is not
+    // positive definite (possible only while gamma = c0/(1+i) > 1, i.e. adaptation before iteration c0) keeps the PREVIOUS
+    // factor -- the host engine does the same (host_mala.cpp::factor); the reference hands Eigen's partial result on.
     for (int j = 0; j < Nv; j++) {
-        const double djj = sqrt(A[(size_t)j * Nv + j]);
+        const double ajj = A[(size_t)j * Nv + j];  // workgroup-uniform
+        if (!(ajj > 0.0)) return;                  // every lane leaves together, L is not touched
+        const double djj = sqrt(ajj);
         __syncthreads();
         if (tid == 0) A[(size_t)j * Nv + j] = djj;
         for (int i = j + 1 + tid; i < Nv; i += TB) A[(size_t)i * Nv + j] = A[(size_t)i * Nv + j] / djj;
@@ -316,9 +320,10 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
             a.logL_cur[Q * C + m] = logL_new;
             a.logPr_cur[Q * C + m] = logPr_new;
             a.logPost_cur[Q * C + m] = logPost_new;
-            a.moved[m] = s_own.acc;
-            a.Pmove[m] = s_own.r;
-            if (m == 0 && s_own.acc) a.counters[1] += 1;
+            // a swap exchanges the pair's moved / Pmove entries too (MALA.cpp:425-446): what is recorded is the partner's
+            a.moved[m] = (src == m) ? s_own.acc : s_partner.acc;
+            a.Pmove[m] = (src == m) ? s_own.r : s_partner.r;
+            if (m == 0 && a.moved[0]) a.counters[1] += 1;
             if (m == 0) a.counters[0] = it;
             if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
                 double *r = a.stats + ((size_t)rec * C + m) * 3;

@@ -12,6 +12,11 @@
 
 using namespace tamcmc;
 
+extern "C" {
+void tamcmc_hip_ctx_attach(tamcmc_hip_ctx *c);  // capi.hip (private)
+void tamcmc_hip_ctx_detach(tamcmc_hip_ctx *c);
+}
+
 struct tamcmc_sampler {
     Config cfg;
     std::unique_ptr<MALA> mala;
@@ -19,6 +24,7 @@ struct tamcmc_sampler {
     std::unique_ptr<DevSampler> dev;  // engine 1: the iteration runs on the GPU, the host objects mirror its state
     long accepted0 = 0;
     tamcmc_hip_ctx *ctx = nullptr;  // borrowed
+    bool attached = false;
     int sync_from_device(bool proposal_too);
 };
 
@@ -121,11 +127,18 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
             if (rc) return rc;
         }
     }
+    tamcmc_hip_ctx_attach(ctx);
+    s->attached = true;
     *out = s.release();
     return TAMCMC_OK;
 }
 
-void tamcmc_sampler_destroy(tamcmc_sampler *s) { delete s; }
+void tamcmc_sampler_destroy(tamcmc_sampler *s) {
+    if (!s) return;
+    tamcmc_hip_ctx *ctx = s->attached ? s->ctx : nullptr;
+    delete s;                       // (its device engine still uses the context's stream here)
+    tamcmc_hip_ctx_detach(ctx);     // frees the context if tamcmc_hip_destroy was called while this sampler lived
+}
 
 int64_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->cur->get_Nvars() : -1; }
 

@@ -139,8 +139,9 @@ const Matrix &MALA::factor(int m) {
         Matrix T = covarmat[(size_t)m];
         for (long i = 0; i < Nvars; i++) T(i, i) += epsi2;
         for (double &v : T.a) v *= sigma[(size_t)m];
-        cholesky_lower(T);
-        Lchol[(size_t)m] = T;
+        // not positive definite (only while gamma = c0/(1+i) > 1): the previous factor stays -- same rule as the device engine
+        // (dev_sampler.hip::adapt_chain); the reference hands Eigen's partially computed factor on (MALA.cpp:348-350)
+        if (cholesky_lower(T) || Lchol[(size_t)m].a.empty()) Lchol[(size_t)m] = T;
         Lchol_valid[(size_t)m] = 1;
     }
     return Lchol[(size_t)m];

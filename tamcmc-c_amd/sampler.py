@@ -97,6 +97,7 @@ class Sampler:
         if st != OK:
             raise TamcmcError(st, "tamcmc_sampler_create: " + self._L.tamcmc_hip_last_error(ctx._h).decode())
         self._h = h
+        ctx._samplers.add(self)  # the context closes its samplers before itself
         self.nvars = int(self._L.tamcmc_sampler_nvars(h))
 
     def close(self):

@@ -244,3 +244,53 @@ def test_packed_stars_reproduce_their_solo_runs(pkg, oracle, synth, engine, grou
         s.close()
     for c in cs:
         c.close()
+
+
+@pytest.mark.parametrize("nchains,nx,dn,wg,c0", [(1, 700, 1, 64, 2.0), (2, 513, 1, 256, 2.0), (3, 100, 2, 64, 2.0), (7, 2049, 1, 64, 2.0),
+                                                 (64, 1500, 1, 64, 2.0), (4, 900, 1, 64, 10.0)])
+def test_engine_matrix_of_awkward_shapes(pkg, oracle, synth, nchains, nx, dn, wg, c0):
+    """Shapes off the beaten path: a single chain (no swap partner), two chains (the pair IS the ladder), odd counts split over two
+    stream groups, the chain cap; spectra shorter than one tile, one bin past a tile boundary, both likelihood-kernel geometries;
+    adaptation from iteration 5 on -- with c0 = 10 the first updates have gamma = c0/(1+i) > 1 and the covariance stops being
+    positive definite (both engines then keep the previous Cholesky factor).  The device-resident engine must follow the
+    host-driven one (same Philox streams, same adaptation) and leave the same counters and move probabilities."""
+    star = _star_with_data(pkg, oracle, synth, nx=nx, seed=nx)
+    c = pkg.HipContext(0, precision=pkg.PRECISION_FAST, workgroup=wg)
+    c.set_spectrum(star.x, star.y)
+    kw = dict(nchains=nchains, lambda_temp=1.2 if nchains > 10 else 1.6, seed=3 + nchains, Nt_learn=(5, 40), periods_learn=(1,), dN_mixing=dn, c0=c0)
+    h = pkg.Sampler(c, star, engine="host", **kw)
+    d = pkg.Sampler(c, star, engine="device", **kw)
+    n = 90
+    sh, th = h.run(n, stats=True)
+    sd, td = d.run(n, stats=True)
+    assert np.isfinite(td).all() and np.isfinite(sd).all()
+    same = np.all(np.isclose(sh, sd, rtol=1e-8, atol=1e-11), axis=(1, 2))
+    first_div = n if same.all() else int(np.argmin(same))
+    # (nearly singular covariance matrices decide "positive definite or not" on the last bits: no trajectory identity asked of c0 = 10)
+    assert first_div >= (30 if c0 < 5 else 6), f"engines diverge at iteration {first_div}"
+    a, b = h.state(), d.state()
+    want_attempts = 0 if nchains == 1 else len([i for i in range(1, n) if i % dn == 0])
+    assert a["iteration"] == b["iteration"] == n and a["swap_attempts"] == b["swap_attempts"] == want_attempts
+    assert b["swaps"] <= want_attempts and (sd[:, 0] != sd[0, 0]).any()
+    if first_div == n:
+        assert a["swaps"] == b["swaps"] and a["accepted0"] == b["accepted0"]
+        assert np.allclose(a["Pmove"], b["Pmove"], rtol=1e-6, atol=1e-9) and np.allclose(a["sigma"], b["sigma"], rtol=1e-7)
+    h.close(); d.close(); c.close()
+
+
+def test_context_and_samplers_can_go_in_any_order(pkg, oracle, synth):
+    """A sampler borrows its context (stream, device buffers).  tamcmc_hip_destroy with samplers still alive only marks the context;
+    the last tamcmc_sampler_destroy releases it -- so garbage collection in arbitrary order cannot touch freed memory."""
+    star = _star_with_data(pkg, oracle, synth, nx=600, seed=1)
+    for engine in ("device", "host"):
+        c = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+        c.set_spectrum(star.x, star.y)
+        s1 = pkg.Sampler(c, star, engine=engine, nchains=3, lambda_temp=1.5, Nt_learn=(10**9, 10**9 + 1), periods_learn=(1,))
+        s2 = pkg.Sampler(c, star, engine=engine, nchains=2, lambda_temp=1.5, Nt_learn=(10**9, 10**9 + 1), periods_learn=(1,))
+        s1.run(5, record=False)
+        L = c._L
+        hc, h1, h2 = c._h, s1._h, s2._h
+        c._h = None; s1._h = None; s2._h = None      # take the handles: the Python layer's own ordering is out of the way
+        L.tamcmc_hip_destroy(hc)                      # context first ...
+        L.tamcmc_sampler_destroy(h1)                  # ... its samplers afterwards
+        L.tamcmc_sampler_destroy(h2)
