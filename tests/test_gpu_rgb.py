@@ -148,3 +148,46 @@ def test_real_red_giant_from_the_reference_files(pkg, oracle):
     assert stat[-40:, 0, 2].mean() > st0["logPost"][0] - 40.0
     s.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("case", [
+    dict(nmax=3, dnu=12.0, DPl=90.0, q=0.2, step=0.05, B=1),                    # the smallest star the model accepts, one vector
+    dict(nmax=6, dnu=18.0, DPl=310.0, q=0.9, step=0.05, B=33, alpha_g=0.9),     # sparse g modes, strong coupling, odd batch
+    dict(nmax=5, dnu=9.0, DPl=70.0, q=0.05, step=0.2, B=3),                     # coarse grid: few points per mixed-mode spacing
+    dict(nmax=8, dnu=7.0, DPl=75.0, q=0.15, step=0.02, B=2, model_type=1, bias_type=2, nferr=9),   # dense spectrum, Hermite bias, from-l0 driver
+    dict(nmax=6, dnu=15.0, DPl=85.0, q=0.3, step=0.05, B=4, cte=True, model_type=1),
+])
+def test_rgb_awkward_stars_match_the_oracle(pkg, oracle, synth, case):
+    """Red-giant stars away from the bench configuration: the device pre-step (pole-structured scan, lane-parallel refinement,
+    sort/unique, zeta normalisation, rows) must deliver the oracle's mixed modes in every regime."""
+    rng = np.random.default_rng(23)
+    cte = case.get("cte", False)
+    params, pl = synth.make_params_rgb_model(rng, nmax=case["nmax"], dnu=case["dnu"], DPl=case["DPl"], q=case["q"], alpha_g=case.get("alpha_g", 0.0),
+                                             model_type=case.get("model_type", 0), bias_type=case.get("bias_type", 1), nferr=case.get("nferr", 4),
+                                             cte_width=cte)
+    model_id = synth.MODEL_RGB_CTE_V4 if cte else synth.MODEL_RGB_V4
+    o = np.cumsum([0] + list(pl))
+    fl0 = params[o[2]:o[3]]
+    lo = fl0.min() - 1.3 * case["dnu"]
+    x = lo + case["step"] * np.arange(int((fl0.max() - fl0.min() + 2.6 * case["dnu"]) / case["step"]))
+    B = case["B"]
+    P = np.tile(params, (B, 1))
+    if B > 1:
+        P[1:, o[3] + 1] *= 1 + 0.004 * rng.standard_normal(B - 1)
+        P[1:, o[3] + 3] *= 1 + 0.05 * rng.standard_normal(B - 1)
+        P[1:, :pl[0]] *= 1 + 0.05 * rng.standard_normal((B - 1, pl[0]))
+    st, m0 = oracle.call_model(model_id, params, pl, x)
+    assert st == 0
+    y = m0 * np.random.default_rng(4).exponential(1.0, m0.size)
+    T = 1.1 ** np.arange(B)
+    ref, m_o, st_o = oracle.loglike_batch(model_id, P, pl, x, y, 1.0, T, want_model=True)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(x, y)
+    got, m_d, st_d = ctx.loglike_params_batch(model_id, P, pl, T, want_model=True)
+    assert np.array_equal(st_d == 0, st_o == 0), (st_d, st_o)
+    ok = st_o == 0
+    assert ok.any()
+    rel = np.linalg.norm(m_d[ok] - m_o[ok], axis=1) / np.linalg.norm(m_o[ok], axis=1)
+    assert rel.max() < 1e-7, rel
+    assert np.allclose(got[ok], ref[ok], rtol=1e-8, atol=0), np.abs(got[ok] / ref[ok] - 1).max()
+    ctx.close()
