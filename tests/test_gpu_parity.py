@@ -325,3 +325,76 @@ def test_many_multiplets_multiple_chunks(pkg, oracle, synth, ctxs):
     c.set_option(pkg.OPT_FD_WINDOWED, 1)
     _, g_w = c.fd_gradient(23, p, pl, idx, h, [1.0], 1.0)
     assert np.all(np.abs(g_w - g_f) <= 5e-14 * x.size / h + 1e-6 * np.max(np.abs(g_f)))
+
+
+def _numpy_table_model(x, mults, noise, nh):
+    """The path's arithmetic written out in numpy (build_lorentzian.cpp:131-246 per component on its window, noise_models.cpp:15-39)."""
+    m = np.zeros_like(x)
+    for r in mults:
+        sl = slice(int(r["i0"]), int(r["i1"]))
+        xs = x[sl]
+        res = np.zeros_like(xs)
+        for k in range(2 * int(r["l"]) + 1):
+            u = 4.0 * (xs - r["nu"][k]) ** 2 / r["gamma"] ** 2
+            prof = r["hv"][k] / (1.0 + u)
+            if r["asym"] != 0.0:
+                prof = prof * ((1.0 + r["asym"] * (xs / r["fc"] - 1.0)) ** 2 + (0.5 * r["gamma"] * r["asym"] / r["fc"]) ** 2)
+            res += prof
+        m[sl] += res
+    for k in range(nh):
+        if noise[3 * k + 1] != 0:
+            m += noise[3 * k] / (1.0 + (1e-3 * noise[3 * k + 1] * x) ** noise[3 * k + 2])
+    return m + noise[-1]
+
+
+@pytest.mark.parametrize("nx", [3, 64, 511, 512, 513, 1025, 4097])
+def test_random_tables_on_awkward_grids(pkg, ctxs, nx):
+    """Table-level entry (tamcmc_hip_loglike_batch) against the formula written out in numpy: grids shorter than a wave, one bin
+    either side of a tile boundary, windows clipped at both ends or one bin wide, zero to 150 multiplets per evaluation (more than
+    one staging chunk), widths from a fraction of a bin to the whole grid, asymmetric profiles, 0-3 Harvey terms, several
+    evaluations of different lengths in one launch -- all three arithmetic modes and both kernel geometries."""
+    rng = np.random.default_rng(nx)
+    step = 0.05
+    x = 1000.0 + step * np.arange(nx)
+    B = 5
+    counts = [0, 1, int(rng.integers(2, 9)), 70, 150]
+    tabs, offsets, noises, nhs = [], [0], [], []
+    for b in range(B):
+        t = np.zeros(counts[b], dtype=pkg.MULT_DTYPE)
+        for r in t:
+            l = int(rng.integers(0, 4))
+            fc = x[0] + rng.uniform(-0.1, 1.1) * (x[-1] - x[0] + step)
+            gam = float(np.exp(rng.uniform(np.log(0.3 * step), np.log(max(nx * step, step)))))
+            i0 = int(rng.integers(0, nx))
+            i1 = int(rng.integers(i0 + 1, nx + 1))
+            if rng.random() < 0.3:
+                i0, i1 = 0, nx
+            r["l"], r["i0"], r["i1"], r["fc"], r["gamma"] = l, i0, i1, fc, gam
+            r["asym"] = rng.choice([0.0, 0.0, rng.uniform(-30, 30)])
+            for k in range(2 * l + 1):
+                r["nu"][k] = fc + (k - l) * rng.uniform(0.0, 0.4)
+                r["hv"][k] = rng.uniform(0.1, 20.0)
+        nh = int(rng.integers(0, 4))
+        nz = np.zeros(10)
+        for k in range(nh):
+            nz[3 * k:3 * k + 3] = [rng.uniform(0.5, 5), rng.uniform(0.2, 2.0), rng.uniform(1.0, 4.0)]
+        nz = np.concatenate([nz[:3 * nh], [rng.uniform(0.2, 2.0)]])
+        noises.append(np.pad(nz, (0, 10 - nz.size)))
+        nhs.append(nh)
+        tabs.append(t)
+        offsets.append(offsets[-1] + t.size)
+    mults = np.concatenate(tabs)
+    noise = np.stack(noises)
+    nn = [3 * h + 1 for h in nhs]
+    ref_m = np.stack([_numpy_table_model(x, tabs[b], noises[b][:nn[b]], nhs[b]) for b in range(B)])
+    y = ref_m[2] * rng.exponential(1.0, nx)
+    T = 1.3 ** np.arange(B)
+    ref_l = np.array([-(y / ref_m[b] + np.log(ref_m[b])).sum() / T[b] for b in range(B)])
+    for name, tol_m, tol_l in (("strict", 1e-12, 1e-12), ("fast_direct", 1e-11, 1e-11), ("fast", 1e-10, 1e-10)):
+        for wg in (64, 256):
+            c = ctxs[name]
+            c.set_option(pkg.OPT_WORKGROUP, wg)
+            c.set_spectrum(x, y)
+            logL, model = c.loglike_batch(mults, np.array(offsets, dtype=np.int32), noise, nhs, nn, T, 1.0, want_model=True)
+            assert np.max(np.abs(model - ref_m) / ref_m) < tol_m, (name, wg, np.max(np.abs(model - ref_m) / ref_m))
+            assert np.allclose(logL, ref_l, rtol=tol_l, atol=1e-9), (name, wg, logL, ref_l)
