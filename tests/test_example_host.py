@@ -58,3 +58,24 @@ def test_example_host_matches_the_python_driven_run(pkg, tmp_path):
     assert np.isclose(float(row[1]), mean[fidx], rtol=1e-7)
     s.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_example_host_fits_the_reference_red_giant(pkg, tmp_path):
+    """The same C++ host on the reference's example red giant (KIC 10722175, red-giant `.model` dialect, io_asymptotic priors): the
+    host-driven engine with the mixed-mode solver on the device, output files in the reference's formats."""
+    from tamcmc_c_amd import sampler
+    root = str(tmp_path / "rgb_")
+    args = ["asymptotic", os.path.join(GOLD, "RGB_10722175.model"), os.path.join(GOLD, "RGB_10722175.data"),
+            os.path.join(GOLD, "sampler_rgb_test.cfg"), os.path.join(GOLD, "errors_rgb_test.cfg"), root]
+    r = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "model_RGB_asympt_aj_AppWidth_HarveyLike_v4 (id 25), 92 parameters (54 free), 6099 bins" in r.stdout
+    cold = sampler.read_params(root, 0)
+    assert cold.shape == (120, 54) and np.isfinite(cold).all() and (cold[1:] != cold[:-1]).any()
+    st = np.fromfile(root + "stat_criteria.bin", dtype="<f8").reshape(120, 3, 4)
+    assert np.isfinite(st).all() and st[:, 2, 0].mean() > st[0, 2, 0] - 50.0
+    hdr = open(root + "params.hdr").read()
+    assert "! Nchains= 4" in hdr and "DP1" in hdr and "ferr_bias" in hdr
+    for f in ("restore_1.dat", "restore_3.dat", "evidence.txt"):
+        assert os.path.exists(root + f)
