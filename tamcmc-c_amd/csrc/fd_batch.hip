@@ -124,12 +124,21 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
             for (int w = 0; w < (int)(sizeof(tamcmc_multiplet) / 8); w++) chg = chg || (pn[w] != po[w]);
         }
         if (chg) {
-            const int pos = atomicAdd(&s_nchg, 1);   // order of the changed rows is irrelevant (a sum)
             const tamcmc_multiplet &rn = a.T.mults[(size_t)slot * per + jdx];
             tamcmc_multiplet ro = a.T.mults[(size_t)(B + slot) * per + jdx];
-            for (int m = 0; m < 7; m++) ro.hv[m] = -ro.hv[m];
-            drows[2 * pos] = rn;
-            drows[2 * pos + 1] = ro;
+            // a parameter that only rescales heights (inclination, visibilities, heights) leaves frequencies, width, asymmetry and
+            // window untouched: +new and -old are then ONE row with the height differences (half the work of the pair)
+            bool amp_only = (rn.l == ro.l) && (rn.i0 == ro.i0) && (rn.i1 == ro.i1) && (rn.fc == ro.fc) && (rn.gamma == ro.gamma) && (rn.asym == ro.asym);
+            for (int m = 0; m < 7; m++) amp_only = amp_only && (rn.nu[m] == ro.nu[m]);
+            const int pos = atomicAdd(&s_nchg, amp_only ? 1 : 2);   // order of the changed rows is irrelevant (a sum)
+            if (amp_only) {
+                for (int m = 0; m < 7; m++) ro.hv[m] = rn.hv[m] - ro.hv[m];
+                drows[pos] = ro;
+            } else {
+                for (int m = 0; m < 7; m++) ro.hv[m] = -ro.hv[m];
+                drows[pos] = rn;
+                drows[pos + 1] = ro;
+            }
             atomicMin(&s_lo, min(rn.i0, ro.i0));
             atomicMax(&s_hi, max(rn.i1, ro.i1));
         }
@@ -144,7 +153,7 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
     if (tid == 0) {
         const int n = s_nchg;
         a.D.pairs[2 * slot] = slot * 2 * per;
-        a.D.pairs[2 * slot + 1] = slot * 2 * per + 2 * n;
+        a.D.pairs[2 * slot + 1] = slot * 2 * per + n;  // n = rows written (one or two per changed multiplet)
         a.D.nh[slot] = a.T.nh[slot];
         a.D.nn[slot] = a.T.nn[slot];
         a.d_flags[slot] = s_noise_chg;
