@@ -138,7 +138,8 @@ def main():
     def make_sampler(use_drift, learn_until):
         eng = "host" if use_drift else a.engine   # the Langevin drift runs on the host-driven engine
         return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=eng,
-                           Nt_learn=(max(learn_until // 2, 1), max(learn_until, 2)), periods_learn=(1,), dN_mixing=a.dn_mixing)
+                           Nt_learn=((learn_until // 2, learn_until) if learn_until >= 2 else (10**9, 10**9 + 1)),  # adaptation ends inside the warm-up
+                           periods_learn=(1,), dN_mixing=a.dn_mixing)
 
     from tamcmc_c_amd import shard
     smp = make_sampler(1 if a.sampler == "mala" else 0, a.warmup)
@@ -181,7 +182,7 @@ def main():
             ck.set_option(pkg.OPT_PRECISION, prec)
             ck.set_spectrum(sk.x, yk)
             pool.append((ck, pkg.Sampler(ck, sk, nchains=a.chains, lambda_temp=lam, seed=107 + k, engine="device", chain_groups=1,
-                                         Nt_learn=(max(a.warmup // 2, 1), max(a.warmup, 2)), periods_learn=(1,), dN_mixing=a.dn_mixing)))
+                                         Nt_learn=((a.warmup // 2, a.warmup) if a.warmup >= 2 else (10**9, 10**9 + 1)), periods_learn=(1,), dN_mixing=a.dn_mixing)))
         ps = [q[1] for q in pool]
         smod.run_packed(ps, a.warmup, record=False)
         torch.cuda.synchronize()

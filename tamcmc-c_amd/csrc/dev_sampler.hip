@@ -633,6 +633,7 @@ struct DevSampler::Impl {
     hipStream_t gst[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_kb[4], ev_ki[4], ev_fork, ev_join[4];
     bool ev_made = false;
+    double *d_pack = nullptr, *h_pack = nullptr;  // state download: device gather block and its pinned host image
 
     template <typename T>
     hipError_t dalloc(T **p, size_t n) {
@@ -651,6 +652,7 @@ DevSampler::~DevSampler() {
         (void)hipStreamSynchronize(impl->ctx->stream);
     }
     for (void *p : impl->allocs) (void)hipFree(p);
+    if (impl->h_pack) (void)hipHostFree(impl->h_pack);
     for (int i = 0; i < impl->n_ev; i++) { (void)hipEventDestroy(impl->ev[i][0]); (void)hipEventDestroy(impl->ev[i][1]); }
     if (impl->ev_made) {
         (void)hipEventDestroy(impl->ev_fork);
@@ -813,6 +815,29 @@ int DevSampler::upload_proposal(int m, const double *L_rowmajor, const double *c
     return TAMCMC_OK;
 }
 
+// gathers the chains' current state into one contiguous block: [vars C Nv | params C Np | logL C | logPr C | logPost C | Pmove C |
+// moved C (as double) | counters 4 (as double: exact below 2^53)]
+__global__ void __launch_bounds__(256) k_pack_state(const DevSamplerArgs a, const int P, double *out) {
+    const size_t C = (size_t)a.C, Np = (size_t)a.desc.Np, Nv = (size_t)a.Nv;
+    const size_t n_v = C * Nv, n_p = C * Np, total = n_v + n_p + 5 * C + 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        double v;
+        if (i < n_v) v = a.vars_cur[(size_t)P * n_v + i];
+        else if (i < n_v + n_p) v = a.params_cur[(size_t)P * n_p + (i - n_v)];
+        else {
+            const size_t r = i - n_v - n_p, k = r / C, m = r - k * C;
+            if (k == 0) v = a.logL_cur[(size_t)P * C + m];
+            else if (k == 1) v = a.logPr_cur[(size_t)P * C + m];
+            else if (k == 2) v = a.logPost_cur[(size_t)P * C + m];
+            else if (k == 3) v = a.Pmove[m];
+            else if (k == 4) v = (double)a.moved[m];
+            else v = (double)a.counters[r - 5 * C];
+        }
+        out[i] = v;
+    }
+}
+
+// One small kernel + ONE copy into pinned memory (eight copies into pageable memory cost ~150 us per tamcmc_sampler_run call).
 int DevSampler::download_state(double *vars, double *params, double *logL, double *logPr, double *logPost, double *Pmove,
                                int *moved, long *counters) {
     Impl &I = *impl;
@@ -821,17 +846,24 @@ int DevSampler::download_state(double *vars, double *params, double *logL, doubl
     const size_t C = (size_t)a.C, Np = (size_t)a.desc.Np, Nv = (size_t)a.Nv;
     hipStream_t st = c->stream;
     DCHK(hipSetDevice(c->device));
-    auto down = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st); };
-    const size_t P = (size_t)I.parity;
-    if (vars) DCHK(down(vars, a.vars_cur + P * C * Nv, C * Nv * 8));
-    if (params) DCHK(down(params, a.params_cur + P * C * Np, C * Np * 8));
-    if (logL) DCHK(down(logL, a.logL_cur + P * C, C * 8));
-    if (logPr) DCHK(down(logPr, a.logPr_cur + P * C, C * 8));
-    if (logPost) DCHK(down(logPost, a.logPost_cur + P * C, C * 8));
-    if (Pmove) DCHK(down(Pmove, a.Pmove, C * 8));
-    if (moved) DCHK(down(moved, a.moved, C * sizeof(int)));
-    if (counters) DCHK(down(counters, a.counters, 4 * sizeof(long)));
+    const size_t n_v = C * Nv, n_p = C * Np, total = n_v + n_p + 5 * C + 4;
+    if (!I.d_pack) {
+        DCHK(I.dalloc(&I.d_pack, total));
+        DCHK(hipHostMalloc((void **)&I.h_pack, total * sizeof(double), hipHostMallocDefault));
+    }
+    hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, I.parity, I.d_pack);
+    DCHK(hipMemcpyAsync(I.h_pack, I.d_pack, total * sizeof(double), hipMemcpyDeviceToHost, st));
     DCHK(hipStreamSynchronize(st));
+    const double *h = I.h_pack;
+    if (vars) std::memcpy(vars, h, n_v * 8);
+    if (params) std::memcpy(params, h + n_v, n_p * 8);
+    const double *sc = h + n_v + n_p;
+    if (logL) std::memcpy(logL, sc, C * 8);
+    if (logPr) std::memcpy(logPr, sc + C, C * 8);
+    if (logPost) std::memcpy(logPost, sc + 2 * C, C * 8);
+    if (Pmove) std::memcpy(Pmove, sc + 3 * C, C * 8);
+    if (moved) for (size_t m = 0; m < C; m++) moved[m] = (int)sc[4 * C + m];
+    if (counters) for (int k = 0; k < 4; k++) counters[k] = (long)sc[5 * C + (size_t)k];
     return TAMCMC_OK;
 }
 
