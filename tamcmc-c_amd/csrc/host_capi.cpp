@@ -181,9 +181,16 @@ int tamcmc_sampler_run_packed(tamcmc_sampler *const *s, int32_t S, int64_t n_ite
     std::vector<int> rc((size_t)S, TAMCMC_OK);
     std::vector<std::thread> th;
     th.reserve((size_t)S);
-    for (int32_t k = 1; k < S; k++)
-        th.emplace_back([&, k] { rc[(size_t)k] = tamcmc_sampler_run(s[k], n_iter, samples ? samples[k] : nullptr, stats ? stats[k] : nullptr); });
+    int32_t started = 1;
+    try {  // (a thread that cannot be started must not unwind through the C boundary: its star runs on this thread instead)
+        for (int32_t k = 1; k < S; k++) {
+            th.emplace_back([&, k] { rc[(size_t)k] = tamcmc_sampler_run(s[k], n_iter, samples ? samples[k] : nullptr, stats ? stats[k] : nullptr); });
+            started = k + 1;
+        }
+    } catch (...) {
+    }
     rc[0] = tamcmc_sampler_run(s[0], n_iter, samples ? samples[0] : nullptr, stats ? stats[0] : nullptr);
+    for (int32_t k = started; k < S; k++) rc[(size_t)k] = tamcmc_sampler_run(s[k], n_iter, samples ? samples[k] : nullptr, stats ? stats[k] : nullptr);
     for (auto &t : th) t.join();
     for (int32_t k = 0; k < S; k++)
         if (rc[(size_t)k]) return rc[(size_t)k];
