@@ -264,7 +264,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic()[0], "traffic_unit": "bytes per launch",
                          "traffic_source": "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                                           "passes, FETCH_SIZE x2 (gfx950), launch shape: " + pmc_traffic()[1] + "; not re-measured live",
+                                           "passes, FETCH_SIZE x2 (gfx950; the guide calibrates the factor on 16 B/lane reads, this kernel reads 8 B/lane, so the "
+                                           "absolute is uncertain within that factor -- either way far below the algorithmic bytes: the spectrum is "
+                                           "served from L2), launch shape: " + pmc_traffic()[1] + "; not re-measured live",
                          "kernel": "k_loglike",
                          "kernel_us_per_launch": k_s * 1e6, "evaluations_per_launch": evals_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
