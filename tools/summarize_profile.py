@@ -47,7 +47,12 @@ if agg:
                       f"(algorithmic bytes of the launch: 16 B x 1e5 bins x 10 evaluations = 16 MB; the spectrum is served from L2)."]
         json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write, "correction": "FETCH_SIZE x2 (gfx950)",
                    "launch": "k_loglike FAST wg=64 K=8, B=10, Nx=1e5", "evaluations": 10}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
-open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(lines) + "\n")
+try:
+    old = open(f"profiles/{tag}_rocprof_summary.md").read()
+    keep = old[old.index("## Other legs"):] if "## Other legs" in old else ""
+except Exception:
+    keep = ""
+open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(lines) + "\n" + ("\n" + keep if keep else ""))
 for f in ks:
     import shutil
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
