@@ -59,6 +59,8 @@ def parse():
                          "rocprofv3 for profiles/, so that the per-kernel averages are those of the headline launches")
     ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
     a = ap.parse_args()
+    a.steps = max(a.steps, 1)
+    a.warmup = max(a.warmup, 0)
     if a.headline_only:
         a.mala_steps, a.packed_stars, a.rgb_steps, a.no_cpu_baseline = 0, 0, 0, True
     return a
