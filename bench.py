@@ -104,6 +104,14 @@ def pmc_traffic():
 
 
 def main():
+    t_proc = time.perf_counter()
+    marks = []  # (label, seconds since the previous mark): where the process's wall time goes besides the timed region
+
+    def mark(label, _t=[t_proc]):
+        now = time.perf_counter()
+        marks.append((label, round(now - _t[0], 3)))
+        _t[0] = now
+
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,8 +152,10 @@ def main():
                            periods_learn=(1,), dN_mixing=a.dn_mixing)
 
     from tamcmc_c_amd import shard
+    mark("imports, library load, synthetic star, spectrum upload")
     smp = make_sampler(1 if a.sampler == "mala" else 0, a.warmup)
     smp.run(a.warmup, record=False)
+    mark("sampler set-up + warm-up steps")
     ctx.reset_kernel_stats()
     acc0 = smp.state()
     # barrier + synchronize on both sides, MAX over ranks (tests/test_multirank_gloo.py covers this on gloo)
@@ -153,6 +163,7 @@ def main():
     k_ms, k_launches, k_evals = ctx.kernel_stats()
     st = smp.state()
     value = shard.aggregate_rate(a.steps, world, elapsed)
+    mark("TIMED REGION (the K steps behind `value`), fences included")
 
     extra = {}
     if a.mala_steps > 0 and a.sampler == "mh" and world == 1:
@@ -170,6 +181,8 @@ def main():
                             "alg_GBps": 16.0 * a.nx * mk_e / max(mk_ms * 1e-3, 1e-12) / 1e9}
         ms.close()
 
+    if extra:
+        mark("extra leg: mala_fd")
     if a.packed_stars > 1 and a.sampler == "mh" and a.engine == "device" and world == 1:
         # Several independent stars on ONE GPU (one context + one device-resident sampler + one host thread per star,
         # tamcmc_sampler_run_packed): a single star's iteration is two short dependent kernels, co-resident stars fill the idle SIMDs.
@@ -201,6 +214,8 @@ def main():
             sk_.close()
             ck.close()
 
+    if "packed" in extra:
+        mark("extra leg: packed (set-up of the co-resident stars + their warm-up + timed steps)")
     if a.rgb_steps > 0 and a.sampler == "mh" and world == 1:
         # BASELINE configs[4] family: red-giant star, mixed modes solved per proposal (csrc/rgb_prestep.hip), 40 tempered chains
         rs = synth.make_c5_star(nx=200000, nmax=10, dnu=10.0, bias_type=1, nferr=6)
@@ -226,6 +241,8 @@ def main():
         rsmp.close()
         rc.close()
 
+    if "c5_rgb" in extra:
+        mark("extra leg: c5_rgb")
     shapes = []
     if world == 1 and a.sampler == "mh" and not a.headline_only:
         # the same kernel at other launch sizes (standalone batched calls through the C ABI, live HIP-event timing): the sampler's
@@ -284,8 +301,12 @@ def main():
             "kernel_time_fraction": k_ms * 1e-3 / elapsed,
         }
         out.update(extra)
+        mark("other launch shapes, mode table for the report")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(star, y, a.chains, lam, a.cpu_seconds)
+            mark("cpu_baseline leg (CPU restatement, bounded sample)")
+        out["wall_seconds"] = {"total_so_far": round(time.perf_counter() - t_proc, 3), "parts": marks,
+                               "note": "`value` = steps / TIMED REGION only; everything else is set-up, warm-up and the extra legs reported above"}
         print(json.dumps(out), flush=True)
     smp.close()
     ctx.close()
