@@ -191,3 +191,24 @@ def test_rgb_awkward_stars_match_the_oracle(pkg, oracle, synth, case):
     assert rel.max() < 1e-7, rel
     assert np.allclose(got[ok], ref[ok], rtol=1e-8, atol=0), np.abs(got[ok] / ref[ok] - 1).max()
     ctx.close()
+
+
+def test_rgb_full_size_c5_matches_the_oracle(pkg, oracle, synth):
+    """BASELINE configs[4] size: 2e5 bins, ~150 mixed modes per vector (the oracle needs ~2 s per evaluation on the host)."""
+    star = synth.make_c5_star(nx=200000, nmax=10, dnu=10.0, bias_type=1, nferr=6)
+    st, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+    assert st == 0
+    y = star.set_spectrum_from_model(m0, 7)
+    rng = np.random.default_rng(9)
+    P = np.tile(star.params, (2, 1))
+    o = np.cumsum([0] + list(star.plength))
+    P[1, o[3] + 1] *= 1.0007          # period spacing: every mixed mode moves
+    P[1, :star.plength[0]] *= 1 + 0.03 * rng.standard_normal(star.plength[0])
+    T = np.array([1.0, 1.15])
+    ref, _, st_o = oracle.loglike_batch(star.model_id, P, star.plength, star.x, y, 1.0, T)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, y)
+    got, _, st_d = ctx.loglike_params_batch(star.model_id, P, star.plength, T)
+    assert (st_o == 0).all() and (st_d == 0).all()
+    assert np.allclose(got, ref, rtol=1e-10, atol=0), np.abs(got / ref - 1).max()
+    ctx.close()
