@@ -106,7 +106,7 @@ int main(int argc, char **argv) {
     for (int64_t done = 0; done < Nsamples; done += chunk) {
         const int64_t n = Nsamples - done < chunk ? Nsamples - done : chunk;
         CHECK(tamcmc_sampler_run(s, n, smp.data(), st.data()), "sampler_run");
-        CHECK(tamcmc_outputs_write_params(root.c_str(), smp.data(), n, C, (int32_t)Nv, Nsamples, relax.data(), plength, Np, params.data(), names.data(),
+        CHECK(tamcmc_outputs_write_params(root.c_str(), smp.data(), n, C, (int32_t)Nv, Nsamples, relax.data(), plength, 11, Np, params.data(), names.data(),
                                           done > 0), "write_params");
         CHECK(tamcmc_outputs_write_stat_criteria(root.c_str(), st.data(), n, C, done > 0), "write_stat_criteria");
         all_stats.insert(all_stats.end(), st.begin(), st.begin() + (size_t)(n * C * 3));

@@ -119,6 +119,15 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *ctx, int model_id, int B, co
                                     const int32_t *plength, const double *Tcoefs, double p, double *logL,
                                     double *model, int32_t *status);
 
+/* Red-giant models (ids 25, 27): the l=1 mixed modes of ONE parameter vector as the device pre-step computes them for the table
+ * (csrc/rgb_prestep.hip) -- what external/ARMM/do_solve.cpp:114-121 prints with the reference's solver:
+ *   nu_m  = solve_mm_asymptotic_O2p / _O2from_l0 (solver_mm.cpp:470-760, chosen by the vector's model_type) + the spline bias,
+ *   zeta  = ksi_fct2(nu_m, ..., "precise") (bump_DP.cpp:125-188),  h1_h0 = h_l_rgb(zeta, Hfactor) (bump_DP.cpp:235-254).
+ * The solver's step is the spectrum's resolution x[2]-x[1] (models.cpp:4719).  Any of nu_m / zeta / h1_h0 ([max_modes]) may be NULL;
+ * *n_modes = number of mixed modes found. */
+int tamcmc_hip_rgb_mixed_modes(tamcmc_hip_ctx *ctx, int model_id, const double *params, int64_t Nparams, const int32_t *plength,
+                               int max_modes, double *nu_m, double *zeta, double *h1_h0, int *n_modes);
+
 /* Forward-difference gradient of the tempered logL (the drift MALA::D_MALA leaves as a stub, MALA.cpp:321-328):
  * for each of the C chains, Nvars+1 evaluations in ONE batched launch.
  * params: C x Nparams; index_to_relax: Nvars parameter indices (model_def.cpp:76-90); hstep: Nvars steps.

@@ -101,14 +101,17 @@ int tamcmc_sampler_read_restore(tamcmc_sampler *s, const char *root, int32_t res
 
 /* ---- the reference's on-disk sample formats (outputs.cpp:1231-1333, :1472-1550) and summary statistics ---- */
 /* <root>params.hdr + <root>params_chain-<m>.bin: raw little-endian doubles [sample][var]; samples = [n x Nchains x Nvars]
- * exactly as tamcmc_sampler_run returns them.  names (may be NULL) = Nparams parameter names for the header. */
+ * exactly as tamcmc_sampler_run returns them.  names (may be NULL) = Nparams parameter names for the header; plength has n_plength
+ * entries (11 for the spectrum models of this build, 10 for the reference's Gaussian-envelope models).
+ * append != 0: a later buffer of the same run -- the .bin files grow and, as in the reference (outputs.cpp:1268), the header is
+ * rewritten with the cumulative `! Nsamples_done` (rows already on disk + n). */
 int tamcmc_outputs_write_params(const char *root, const double *samples, int64_t n, int32_t Nchains, int32_t Nvars,
-                                int64_t Nsamples_total, const int32_t *relax, const int32_t *plength, int64_t Nparams,
+                                int64_t Nsamples_total, const int32_t *relax, const int32_t *plength, int32_t n_plength, int64_t Nparams,
                                 const double *inputs, const char *const *names, int32_t append);
 /* <root>stat_criteria.hdr/.bin: per sample logLikelihood[0:Nchains], logPrior[0:Nchains], logPosterior[0:Nchains];
- * stats = [n x Nchains x 3] as tamcmc_sampler_run returns them. */
+ * stats = [n x Nchains x 3] as tamcmc_sampler_run returns them; append as above (outputs.cpp:1502). */
 int tamcmc_outputs_write_stat_criteria(const char *root, const double *stats, int64_t n, int32_t Nchains, int32_t append);
-/* reads back one chain (what tools/bin2txt_params.cpp does); samples may be NULL to query the count */
+/* reads back one chain (what tools/bin2txt_params.cpp does): the header's Nsamples_done rows; samples may be NULL to query the count */
 int tamcmc_outputs_read_params(const char *root, int32_t chain, double *samples, int64_t max_samples, int64_t *n_read,
                                int32_t *Nchains, int32_t *Nvars);
 /* mean, median, population standard deviation per variable (tools/quick_samples_stats.cpp:4-35 via bin2txt_params.cpp:165-168);

@@ -8,11 +8,15 @@
  *   cubic / Hermite spline of the frequency bias               external/spline/src/spline.h:208-505 (ttk592/spline, vendored)
  * Plain C restatement written from reading those files for MEANING; every function cites the lines it follows.
  *
- * Pinning status: PARITY UNPINNED.  external/ARMM/TEST_EXPECTED_OUTPUTS.txt holds printed mixed-mode frequencies, but the
- * test functions that produced them (test_sg_solver_mm, test_asymptotic_sg_O2from_l0, test_make_synthetic_asymptotic_star_*)
- * are no longer defined anywhere in the reference tree (only their commented-out calls remain: external/ARMM/test.cpp:23-52),
- * so their inputs cannot be recovered.  The functions here are pinned by analytic known-answer tests only
- * (tests/test_oracle_rgb.py: q -> 0 limit, pure p/g asymptotics, zeta in [0,1], spline reproduces its nodes and a parabola).
+ * Pinning status: PINNED on outputs of the reference's own solver.  external/ARMM/tests/scanner/out/out_{0..10}.res are written by
+ * external/ARMM/do_solve.cpp:114-121 (solve_mm_asymptotic_O2from_l0 -> ksi_fct2 "precise" -> h_l_rgb) with every input printed in
+ * their `!` header (q = 0 .. 1); copies live in tests/golden/armm_scanner/ and tests/test_armm_scanner_fixtures.py requires
+ * orc_armm_solve_O2from_l0 + orc_ksi_fct2_precise + the H1/H0 law to reproduce nu_p, dnu_p, nu_g, DPg, nu_m, zeta_pg and H1/H0 to the
+ * printed six significant digits for all 11 files (they do: max relative deviation 5e-6 = the print rounding).
+ * Not covered by those files, hence still pinned by analytic known-answer tests only (tests/test_oracle_rgb.py): the O2p driver
+ * (model_type 0; it shares solver_mm and the pair loop with the pinned driver), the bias spline (reproduces its nodes / a parabola),
+ * and the width / splitting laws of the mixed modes.  (external/ARMM/TEST_EXPECTED_OUTPUTS.txt belongs to test functions that no
+ * longer exist in the reference tree: unusable.)
  * The solver's grid is Eigen::LinSpaced in the reference, whose rounding differs between Eigen versions: solutions agree to
  * ~resol*factor, not to the bit.
  */

@@ -56,6 +56,7 @@ ABI = [
     ("tamcmc_hip_fd_gradient", C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int64, _ip, _ip, C.c_int, _dp, _dp, C.c_double, _dp, _dp]),
     ("tamcmc_hip_fd_gradient_posterior", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, C.c_int64, _ip, _ip, C.c_int, _dp, _dp, C.c_double,
                                                   _dp, _ip, _dp, _dp, _dp, _dp, _dp]),
+    ("tamcmc_hip_rgb_mixed_modes", C.c_int, [_vp, C.c_int, _dp, C.c_int64, _ip, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     ("tamcmc_hip_get_kernel_stats", C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("tamcmc_hip_reset_kernel_stats", C.c_int, [_vp]),
 ]
@@ -218,6 +219,16 @@ class HipContext:
         self._chk(st, tolerate=(ERR_EMPTY_WINDOW, ERR_NAN_WINDOW))
         self.last_grad_prior = gp
         return l0, pr0, g
+
+    def rgb_mixed_modes(self, model_id, params, plength, max_modes=1024):
+        """l=1 mixed modes of one red-giant vector from the device pre-step: (nu_m, zeta, H1/H0) -- what ARMM's do_solve prints."""
+        params, plength = _f64(params), _i32(plength)
+        nu, z, h = np.zeros(max_modes), np.zeros(max_modes), np.zeros(max_modes)
+        n = C.c_int(0)
+        self._chk(self._L.tamcmc_hip_rgb_mixed_modes(self._h, int(model_id), _p(params), params.size, _p(plength, _ip), max_modes,
+                                                     _p(nu), _p(z), _p(h), C.byref(n)))
+        k = min(n.value, max_modes)
+        return nu[:k].copy(), z[:k].copy(), h[:k].copy()
 
     def kernel_stats(self):
         ms, n, e = C.c_double(0), C.c_int64(0), C.c_int64(0)

@@ -284,6 +284,37 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *c, int model_id, int B, cons
     return first_err;
 }
 
+// The l=1 mixed modes of one red-giant parameter vector, as the device pre-step computes them for the likelihood table.
+int tamcmc_hip_rgb_mixed_modes(tamcmc_hip_ctx *c, int model_id, const double *params, int64_t Nparams, const int32_t *plength,
+                               int max_modes, double *nu_m, double *zeta, double *h1_h0, int *n_modes) {
+    if (!c || !params || !plength || !n_modes || max_modes < 0 || Nparams < 1) return TAMCMC_ERR_BAD_ARG;
+    if (c->Nx <= 0) return TAMCMC_ERR_NO_SPECTRUM;
+    if (model_id != TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID && model_id != TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4_ID) return TAMCMC_ERR_BAD_MODEL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int per = 0, stride = 1, first_err = TAMCMC_OK, rot = 0;
+    int32_t status = TAMCMC_OK;
+    int rc = tamcmc::rgb_stage_params(c, model_id, 1, params, Nparams, plength, &status, &per, &stride, &first_err, &rot);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tamcmc::rgb_collect_status(c, 1, &status, &first_err);
+    if (status != TAMCMC_OK) return status;
+    std::vector<double> z((size_t)(max_modes > 0 ? max_modes : 1));
+    rc = tamcmc::rgb_fetch_modes(c, 1, 0, max_modes, nu_m, z.data(), n_modes);
+    if (rc) return rc;
+    const int n = *n_modes < max_modes ? *n_modes : max_modes;
+    // height ratio law h_l_rgb (bump_DP.cpp:235-254) with the vector's Hfactor (the l=1 block's 8th entry, models.cpp:4760)
+    const double Hfactor = std::fabs(params[plength[0] + plength[1] + plength[2] + 7]);
+    for (int i = 0; i < n; i++) {
+        if (zeta) zeta[i] = z[(size_t)i];
+        if (h1_h0) {
+            double hr = std::sqrt(1. - Hfactor * z[(size_t)i]);
+            if (hr > -1e-5 && hr < 1e-5) hr = 1e-10;
+            h1_h0[i] = hr;
+        }
+    }
+    return TAMCMC_OK;
+}
+
 int tamcmc_hip_get_kernel_stats(tamcmc_hip_ctx *c, double *kernel_ms_total, int64_t *launches, int64_t *evaluations) {
     if (!c) return TAMCMC_ERR_BAD_ARG;
     if (kernel_ms_total) *kernel_ms_total = c->kernel_ms;

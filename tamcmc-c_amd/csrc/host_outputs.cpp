@@ -17,40 +17,71 @@
 
 #include "../../include/tamcmc_sampler.h"
 
+namespace {
+// One row of numbers the way the reference streams them: `stream << eigen_vector.transpose()` (Eigen's default IOFormat) prints
+// every coefficient with the stream's precision (6 unless set), right-aligned to the width of the widest one, separated by " ".
+std::string eigen_row(const double *v, int64_t n, int precision = 6) {
+    std::vector<std::string> t((size_t)n);
+    size_t w = 0;
+    char buf[64];
+    for (int64_t i = 0; i < n; i++) {
+        std::snprintf(buf, sizeof buf, "%.*g", precision, v[i]);
+        t[(size_t)i] = buf;
+        w = std::max(w, t[(size_t)i].size());
+    }
+    std::string out;
+    for (int64_t i = 0; i < n; i++) {
+        if (i) out += " ";
+        out.append(w - t[(size_t)i].size(), ' ');
+        out += t[(size_t)i];
+    }
+    return out;
+}
+std::string eigen_row_int(const int32_t *v, int64_t n) {
+    std::vector<double> d((size_t)n);
+    for (int64_t i = 0; i < n; i++) d[(size_t)i] = (double)v[i];
+    return eigen_row(d.data(), n, 17);
+}
+// rows already in a raw [sample][...] file of `row_bytes` per sample (0 when absent): the samples written by earlier buffers
+int64_t rows_on_disk(const std::string &file, size_t row_bytes) {
+    std::ifstream f(file.c_str(), std::ifstream::binary);
+    if (!f.is_open() || row_bytes == 0) return 0;
+    f.seekg(0, std::ios::end);
+    return (int64_t)f.tellg() / (int64_t)row_bytes;
+}
+}  // namespace
+
 extern "C" {
 
+// Outputs::write_bin_params (outputs.cpp:1231-1333).  Like the reference, the ASCII header is rewritten with EVERY buffer and carries
+// the cumulative sample count (outputs.cpp:1268: Nbuffer*Ncopy + counts + Nsamples_sofar) -- its tools read exactly Nsamples_done
+// rows (getstats.cpp:156, getevidence.cpp:197); append != 0 = a later buffer of the same run (the .bin files grow).
 int tamcmc_outputs_write_params(const char *root, const double *samples, int64_t n, int32_t Nchains, int32_t Nvars,
-                                int64_t Nsamples_total, const int32_t *relax, const int32_t *plength, int64_t Nparams,
+                                int64_t Nsamples_total, const int32_t *relax, const int32_t *plength, int32_t n_plength, int64_t Nparams,
                                 const double *inputs, const char *const *names, int32_t append) {
-    if (!root || !samples || n < 0 || Nchains < 1 || Nvars < 1 || !relax || !plength || !inputs) return TAMCMC_ERR_BAD_ARG;
+    if (!root || !samples || n < 0 || Nchains < 1 || Nvars < 1 || !relax || !plength || n_plength < 1 || !inputs) return TAMCMC_ERR_BAD_ARG;
     const std::string base(root);
-    if (!append) {
+    const int64_t before = append ? rows_on_disk(base + "params_chain-0.bin", sizeof(double) * (size_t)Nvars) : 0;
+    {
         std::ofstream h((base + "params.hdr").c_str());
         if (!h.is_open()) return TAMCMC_ERR_BAD_ARG;
         h << "# This is the header file of the BINARY output file for the model parameters \n";
         h << "# This file contains values for vars[0:Nchains-1][ 0:Nvars-1]. Each matrix is in a different file, indexed by the chain number\n";
         h << "! Nsamples= " << Nsamples_total << "\n";
         h << "! Nchains= " << Nchains << "\n";
-        h << "! Nsamples_done=" << n << "\n";
+        h << "! Nsamples_done=" << (before + n) << "\n";
         h << "! Nvars= " << Nvars << "\n";
         h << "! Ncons= " << (Nparams - Nvars) << "\n";
-        h << "! relax= ";
-        for (int64_t i = 0; i < Nparams; i++) h << relax[i] << (i + 1 < Nparams ? " " : "");
-        h << "\n! plength= ";
-        for (int i = 0; i < 11; i++) h << plength[i] << (i < 10 ? " " : "");
-        h << "\n! constant_names= ";
-        bool any_cons = false;
+        h << "! relax= " << eigen_row_int(relax, Nparams) << "\n";
+        h << "! plength= " << eigen_row_int(plength, n_plength) << "\n";
+        h << "! constant_names= ";
+        std::vector<double> cons;
         for (int64_t i = 0; i < Nparams; i++)
-            if (relax[i] != 1) { h << (names ? names[i] : ("p" + std::to_string(i)).c_str()) << "   "; any_cons = true; }
-        if (!any_cons) h << "None   ";
+            if (relax[i] != 1) { h << (names ? names[i] : ("p" + std::to_string(i)).c_str()) << "   "; cons.push_back(inputs[i]); }
+        if (cons.empty()) h << "None   ";
         h << "\n! constant_values= ";
-        if (!any_cons) h << "-1";
-        else {
-            h.precision(12);
-            bool first = true;
-            for (int64_t i = 0; i < Nparams; i++)
-                if (relax[i] != 1) { h << (first ? "" : " ") << inputs[i]; first = false; }
-        }
+        if (cons.empty()) h << "-1";
+        else h << eigen_row(cons.data(), (int64_t)cons.size());  // the reference streams them at the default 6 significant digits
         h << "\n! variable_names=";
         for (int64_t i = 0; i < Nparams; i++)
             if (relax[i] == 1) h << (names ? names[i] : ("p" + std::to_string(i)).c_str()) << "   ";
@@ -67,18 +98,20 @@ int tamcmc_outputs_write_params(const char *root, const double *samples, int64_t
     return TAMCMC_OK;
 }
 
+// Outputs::write_bin_stat_criteria (outputs.cpp:1472-1550); header rewritten per buffer with the cumulative count (:1502)
 int tamcmc_outputs_write_stat_criteria(const char *root, const double *stats, int64_t n, int32_t Nchains, int32_t append) {
     if (!root || !stats || n < 0 || Nchains < 1) return TAMCMC_ERR_BAD_ARG;
     const std::string base(root);
-    if (!append) {
+    const int64_t before = append ? rows_on_disk(base + "stat_criteria.bin", sizeof(double) * 3 * (size_t)Nchains) : 0;
+    {
         std::ofstream h((base + "stat_criteria.hdr").c_str());
         if (!h.is_open()) return TAMCMC_ERR_BAD_ARG;
         h << "# This is the header of the BINARY output file for the statistical information.\n";
         h << "# This file contains values for the logLikelihood (columns 0:Nchains-1), logPrior (columns Nchains:2*Nchains-1) and logPosterior (columns 2*Nchains:3*Nchains-1),  \n";
-        h << "! Nsamples_done=" << n << "\n";
+        h << "! Nsamples_done=" << (before + n) << "\n";
         h << "! Nchains= " << Nchains << "\n";
         h << "! labels= ";
-        const char *labels[3] = {"logLikelihood", "logPrior", "logPosterior"};
+        const char *labels[3] = {"logLikelihood", "logPrior", "logPosteriors"};  // (sic, outputs.cpp:1485)
         for (int k = 0; k < 3; k++)
             for (int i = 0; i < Nchains; i++) h << labels[k] << "[" << i << "]   ";
         h << "\n";
@@ -100,10 +133,12 @@ int tamcmc_outputs_read_params(const char *root, int32_t chain, double *samples,
     std::ifstream h((base + "params.hdr").c_str());
     if (!h.is_open()) return TAMCMC_ERR_BAD_ARG;
     int nv = -1, nc = -1;
+    int64_t done = -1;
     std::string line;
     while (std::getline(h, line)) {
         if (line.rfind("! Nvars=", 0) == 0) nv = std::atoi(line.substr(8).c_str());
         if (line.rfind("! Nchains=", 0) == 0) nc = std::atoi(line.substr(10).c_str());
+        if (line.rfind("! Nsamples_done=", 0) == 0) done = std::atoll(line.substr(16).c_str());
     }
     if (nv < 1 || nc < 1 || chain < 0 || chain >= nc) return TAMCMC_ERR_BAD_ARG;
     *Nvars = nv;
@@ -111,7 +146,8 @@ int tamcmc_outputs_read_params(const char *root, int32_t chain, double *samples,
     std::ifstream f((base + "params_chain-" + std::to_string(chain) + ".bin").c_str(), std::ifstream::binary);
     if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
     f.seekg(0, std::ios::end);
-    const int64_t total = (int64_t)f.tellg() / (int64_t)(sizeof(double) * (size_t)nv);
+    int64_t total = (int64_t)f.tellg() / (int64_t)(sizeof(double) * (size_t)nv);
+    if (done >= 0 && done < total) total = done;  // the reference's tools read exactly Nsamples_done rows (getstats.cpp:156)
     f.seekg(0, std::ios::beg);
     const int64_t n = samples ? std::min(total, max_samples) : 0;
     if (n > 0) f.read(reinterpret_cast<char *>(samples), (std::streamsize)(sizeof(double) * (size_t)nv * (size_t)n));
@@ -202,13 +238,15 @@ int tamcmc_outputs_write_evidence(const char *file, int64_t n_samples, int32_t N
         std::fprintf(f, "# col(1): Number of samples used to compute the evidence \n");
         std::fprintf(f, "# col(2:2+Nchains): averaged probability <P(D|M,I)> over the samples of each chain \n");
         std::fprintf(f, "# col(2+Nchains+1): Evidence P(M|D, I) computed by (1) interpolation and (2) averaging \n");
-        std::fprintf(f, "! beta=");
-        for (int32_t m = 0; m < Nchains; m++) std::fprintf(f, "%s%.6g", m ? " " : "", beta[m]);
-        std::fprintf(f, "\n! interpolation_factor=%d\n", (int)interp_factor);
+        std::fprintf(f, "! beta=%s\n", eigen_row(beta, Nchains).c_str());
+        std::fprintf(f, "! interpolation_factor=%d\n", (int)interp_factor);
     }
-    std::fprintf(f, "%lld ", (long long)n_samples);
+    // the reference streams an Eigen row behind std::setw(20) << std::setprecision(10) (diagnostics.cpp:1048-1052): the pending
+    // width pads Eigen's empty matrix prefix to 20 blanks and every coefficient to 20 columns; Eigen then RESTORES the width, so the
+    // " " that follows is padded to 20 columns as well, and the evidence takes its own setw(20)
+    std::fprintf(f, "%lld %20s", (long long)n_samples, "");
     for (int32_t m = 0; m < Nchains; m++) std::fprintf(f, "%s%20.10g", m ? " " : "", L_beta[m]);
-    std::fprintf(f, " %20.10g\n", evidence);
+    std::fprintf(f, "%20s%20.10g\n", "", evidence);
     return std::fclose(f) == 0 ? TAMCMC_OK : TAMCMC_ERR_BAD_ARG;
 }
 
@@ -222,10 +260,18 @@ int tamcmc_outputs_write_evidence(const char *file, int64_t n_samples, int32_t N
 // rows at the default 6, so its restart is lossy), and the *_mean blocks (averages over the reference's output buffer, which
 // this build does not keep) repeat the last values.
 namespace {
+// comment block + size keys of one restore file, line for line as Outputs::write_buffer_restore writes them (outputs.cpp:874-894,
+// :926-946, :981-1001); `dr` = the wording of the three "Use this" lines, which differs between file 1 and files 2/3
 void restore_header(std::ofstream &f, int file_no, const char *what, int Nchains, int Nvars, int64_t iteration, const char *const *names) {
+    const char *dr = file_no == 1 ? "do_restore_[X]=1" : "do_restore=1";
+    const char *dp = file_no == 1 ? "do_restore_proposal=1" : "do_restore=1";
     f << "# This is an output file containing what is required to restore a run to its last saved position \n";
     f << "# File number: " << file_no << " \n";
     f << "# Contains " << what << "\n";
+    f << "# Use this if you wish to: \n";
+    f << "#       (1) complete a finished job that requires more samples ==> set erase_old_file=0 and " << dr << " \n";
+    f << "#       (2) restart a finished job by ignoring old samples (e.g. ignoring a Burn-in) ==> set erase_old_file=1 and " << dp << " \n";
+    f << "#       (3) terminate an unfinished job which failed to finished (e.g. due to computer unexpected shutdown) ==> set erase_old_file=0 and " << dr << " \n";
     f << "! Nchains= " << Nchains << "\n";
     f << "! Nvars= " << Nvars << "\n";
     f << "! iteration=" << iteration << "\n";
@@ -233,14 +279,8 @@ void restore_header(std::ofstream &f, int file_no, const char *what, int Nchains
     for (int i = 0; i < Nvars; i++) f << (names && names[i] ? names[i] : "var") << "   ";
     f << "\n";
 }
-void put_row(std::ofstream &f, const double *v, int n) {
-    char buf[40];
-    for (int i = 0; i < n; i++) {
-        std::snprintf(buf, sizeof buf, "%.17g", v[i]);
-        f << (i ? " " : "") << buf;
-    }
-    f << "\n";
-}
+// one matrix row, aligned like an Eigen row but with 17 significant digits (lossless restart; the reference: 6)
+void put_row(std::ofstream &f, const double *v, int n) { f << eigen_row(v, n, 17) << "\n"; }
 // numbers following `key` in a restore file: on the key's own line after '=', then on the following lines until the next
 // line starting with '!' or '#'; lines starting with '*' (chain markers) are skipped
 bool read_block(const std::string &path, const std::string &key, size_t want, std::vector<double> &out, int *Nchains, int *Nvars,
@@ -283,7 +323,7 @@ extern "C" int tamcmc_outputs_write_restore(const char *root, int32_t Nchains, i
     {
         std::ofstream f((base + "1.dat").c_str());
         if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
-        restore_header(f, 1, "the last values for the variables vars[0:Nchain-1]. vars_mean denotes averaged values of Nbuffer", Nchains, Nvars,
+        restore_header(f, 1, "the last values for the variables vars[0:Nchain-1]. vars_mean denotes averaged values of Nbuffer ", Nchains, Nvars,
                        iteration, names);
         for (const char *key : {"! vars= ", "! vars_mean= "}) {
             f << key << "\n";
@@ -293,7 +333,8 @@ extern "C" int tamcmc_outputs_write_restore(const char *root, int32_t Nchains, i
     {
         std::ofstream f((base + "2.dat").c_str());
         if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
-        restore_header(f, 2, "the last values of (a) sigmas[0:Nchains-1] and (b) mus[0:Nchains-1, 0:Nvars-1]", Nchains, Nvars, iteration, names);
+        restore_header(f, 2, "the last values of (a) sigmas[0:Nchains-1] and (b) mus[0:Nchains-1, 0:Nvars-1].  sigmas_mean and mus_mean denotes averaged values of Nbuffer",
+                       Nchains, Nvars, iteration, names);
         for (int pass = 0; pass < 2; pass++) {
             f << (pass ? "! sigmas_mean= " : "! sigmas= ");
             put_row(f, sigmas, Nchains);
@@ -304,8 +345,8 @@ extern "C" int tamcmc_outputs_write_restore(const char *root, int32_t Nchains, i
     {
         std::ofstream f((base + "3.dat").c_str());
         if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
-        restore_header(f, 3, "the last value of the covariance matrix covarmats[0:Nchains-1, 0:Nvars-1, 0:Nvars-1]", Nchains, Nvars, iteration,
-                       names);
+        restore_header(f, 3, "the last value of the covariance matrix covarmats[0:Nchains-1, 0:Nvars-1, 0:Nvars-1]. covarmats_mean denotes the averaged values over Nbuffer",
+                       Nchains, Nvars, iteration, names);
         for (const char *key : {"! covarmats= ", "! covarmats_mean= "}) {
             f << key << "\n";
             for (int m = 0; m < Nchains; m++) {

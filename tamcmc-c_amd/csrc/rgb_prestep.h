@@ -12,6 +12,8 @@ namespace tamcmc {
 // tile_rot = launch-order hint for k_loglike.
 int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *params, int64_t Nparams, const int32_t *plength, int32_t *status,
                      int *per_out, int *stride_out, int *first_err, int *tile_rot_out);
+// after rgb_stage_params(B) + a stream synchronisation: vector b's mixed-mode frequencies and normalised zeta (at most max_modes each)
+int rgb_fetch_modes(tamcmc_hip_ctx *c, int B, int b, int max_modes, double *nu_m, double *zeta, int *n_out);
 // after the caller's stream synchronisation: device-side status words -> status[] / first_err
 void rgb_collect_status(tamcmc_hip_ctx *c, int B, int32_t *status, int *first_err);
 }  // namespace tamcmc

@@ -749,6 +749,34 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     return TAMCMC_OK;
 }
 
+// After rgb_stage_params(B) and a stream synchronisation: vector b's mixed modes as the pre-step left them in the workspace --
+// frequencies (spline bias included) and the normalised zeta function, clipped at 1 like ksi_fct2_precise (bump_DP.cpp:180-186).
+int rgb_fetch_modes(tamcmc_hip_ctx *c, int B, int b, int max_modes, double *nu_m, double *zeta, int *n_out) {
+    using namespace rgb;
+    const size_t bytes_prep = ((size_t)B * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)B * sizeof(RowIn) + 15) & ~(size_t)15;
+    const size_t nsolbuf = (size_t)B * MAXSOL;
+    unsigned char *base = c->d_rgb.p;
+    const double *d_sols = (const double *)(base + bytes_prep + bytes_rows);
+    const double *d_fl1 = d_sols + nsolbuf, *d_ksi = d_fl1 + nsolbuf;
+    const unsigned long long *d_norm = (const unsigned long long *)(d_ksi + nsolbuf);
+    const int *d_nsol = (const int *)(d_norm + B);
+    int n = 0;
+    unsigned long long nb = 0;
+    HIPCHK(c, hipMemcpy(&n, d_nsol + b, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&nb, d_norm + b, sizeof nb, hipMemcpyDeviceToHost));
+    if (n < 0 || n > MAXSOL) return TAMCMC_ERR_BAD_ARG;
+    *n_out = n;
+    if (n > max_modes) n = max_modes;
+    if (n > 0 && nu_m) HIPCHK(c, hipMemcpy(nu_m, d_fl1 + (size_t)b * MAXSOL, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (n > 0 && zeta) {
+        HIPCHK(c, hipMemcpy(zeta, d_ksi + (size_t)b * MAXSOL, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        double norm;
+        std::memcpy(&norm, &nb, sizeof norm);
+        for (int i = 0; i < n; i++) { zeta[i] = zeta[i] / norm; if (zeta[i] > 1) zeta[i] = 1; }
+    }
+    return TAMCMC_OK;
+}
+
 // After the stream has been synchronised: merges the device-side status words into status[] / first_err.
 void rgb_collect_status(tamcmc_hip_ctx *c, int B, int32_t *status, int *first_err) {
     using namespace rgb;

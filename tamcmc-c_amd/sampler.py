@@ -34,7 +34,7 @@ EXTRA_ABI += [
     ("tamcmc_outputs_read_restore", C.c_int, [C.c_char_p, _ip, _ip, _i64p, _dp, _dp, _dp, _dp]),
     ("tamcmc_sampler_write_restore", C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_char_p)]),
     ("tamcmc_sampler_read_restore", C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]),
-    ("tamcmc_outputs_write_params", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, C.c_int64, _dp,
+    ("tamcmc_outputs_write_params", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _ip, _ip, C.c_int32, C.c_int64, _dp,
                                              C.POINTER(C.c_char_p), C.c_int32]),
     ("tamcmc_outputs_write_stat_criteria", C.c_int, [C.c_char_p, _dp, C.c_int64, C.c_int32, C.c_int32]),
     ("tamcmc_outputs_read_params", C.c_int, [C.c_char_p, C.c_int32, _dp, C.c_int64, _i64p, _ip, _ip]),
@@ -198,8 +198,9 @@ def write_outputs(root, star, samples, stats=None, nsamples_total=None, append=F
     smp = _f64(samples)
     n, nc, nv = smp.shape
     names = (C.c_char_p * len(star.names))(*[s.encode() for s in star.names])
+    pl = _i32(star.plength)
     st = L.tamcmc_outputs_write_params(str(root).encode(), _p(smp), n, nc, nv, int(nsamples_total or n), _p(_i32(star.relax), _ip),
-                                       _p(_i32(star.plength), _ip), star.params.size, _p(_f64(star.params)), names, int(append))
+                                       _p(pl, _ip), pl.size, star.params.size, _p(_f64(star.params)), names, int(append))
     if st != OK:
         raise TamcmcError(st, "tamcmc_outputs_write_params")
     if stats is not None:
