@@ -50,10 +50,15 @@ typedef struct tamcmc_sampler_config {
     /* additions of this build */
     uint64_t seed;                 /* counter-based RNG seed (the reference seeds libc rand() with time(NULL)) */
     double fd_step_rel;            /* forward-difference step = fd_step_rel * max(|theta_k|, 1e-3); 0 -> 1e-7 */
-    int32_t chain_groups;          /* device engine: the chains run as this many groups on separate HIP streams (one group's proposal
-                                      kernel overlaps another's likelihood kernel).  0 = default (2 from 8 chains on, or the
-                                      TAMCMC_CHAIN_GROUPS environment variable); use 1 when several stars share a GPU
+    int32_t chain_groups;          /* device engine, lockstep scheme (iterations with adaptation): the chains run as this many groups
+                                      on separate HIP streams (one group's proposal kernel overlaps another's likelihood kernel).
+                                      0 = default (2 from 8 chains on); use 1 when several stars share a GPU
                                       (tamcmc_sampler_run_packed): the co-resident stars already fill each other's gaps */
+    int32_t swap_rule;             /* what chain B = A+1 stores as logPosterior after an accepted parallel-tempering swap:
+                                      0 = logL_A(T_B) + logPrior_A, the posterior of the position it receives (default);
+                                      1 = the reference as executed: MALA.cpp:433 overwrites logPrior[A] with B's before MALA.cpp:444
+                                          reads it, so B stores logL_A(T_B) + its OWN OLD prior (that value enters B's next MH ratio,
+                                          MALA.cpp:515, until B accepts a move) */
 } tamcmc_sampler_config;
 
 /* The context must already hold the spectrum (tamcmc_hip_set_spectrum). It is borrowed, not owned: the sampler uses its stream and
@@ -73,6 +78,12 @@ int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, doubl
  * run on its own (no shared state, random numbers addressed by (seed, chain, iteration)).  samples / stats: S pointers (or NULL
  * arrays / NULL entries).  Returns the first non-zero status. */
 int tamcmc_sampler_run_packed(tamcmc_sampler *const *s, int32_t S, int64_t n_iter, double *const *samples, double *const *stats);
+
+/* The random numbers iteration `iteration` consumes -- the counter-based streams (csrc/rng.h) that replace the reference's
+ * rand() (MALA.cpp:62-63, random_JB.cpp:99-105,255), pure functions of (seed, chain, iteration): z [Nchains x Nvars] = the normals of
+ * new_prop_values (MALA.cpp:352), u_accept [Nchains] = the comparators of update_position_MH (MALA.cpp:467,536), *u_swap / *ind_A = the
+ * comparator and first chain of parallel_tempering (MALA.cpp:400,406).  Lets a caller replay or audit any step. Pointers may be NULL. */
+int tamcmc_sampler_draws(const tamcmc_sampler *s, int64_t iteration, double *z, double *u_accept, double *u_swap, int32_t *ind_A);
 
 /* Current state. Any pointer may be NULL.
  *   vars [Nchains x Nvars], logL/logPrior/logPost/Pmove/sigma [Nchains], counters [4] = iteration, accepted moves

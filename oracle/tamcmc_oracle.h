@@ -166,6 +166,32 @@ long double orc_priors_asymptotic(const double *params, const int *plength, cons
 double orc_call_prior(int prior_class, const double *params, const int *plength, const double *priors,
                       const int *priors_names_switch, const double *extra_priors);
 
+/* ---- one sampler iteration with explicit random draws (sampler_oracle.c; MALA.cpp:135-176, :296-319, :339-369, :397-461, :463-553,
+ *      :645-703; model_def.cpp:466-482) ---- */
+typedef struct orc_sampler_star {  /* what Config::setup hands the sampler: the star, its model class, the !MALA scalars */
+    int model_id, prior_class;
+    long Nparams, Nvars, Nx, Nchains;
+    const int *plength, *index_to_relax, *priors_switch;
+    const double *priors, *extra_priors, *x, *y, *Tcoefs, *init_logL;
+    double likelihood_params, epsilon1, epsi2, A1, target_acceptance, c0;
+} orc_sampler_star;
+long double orc_p1_fct(long double x, long double epsilon1, long double A1);
+void orc_p2_fct(double *M, long n, double A1);
+void orc_p3_fct(double *v, long n, double A1);
+void orc_update_proposal(double *mu, double *covarmat, double *sigma, const double *vars, long Nvars, long double acceptance,
+                         long double gamma, long double target_acceptance, long double epsilon1, long double A1);
+int orc_new_prop_values(const double *covarmat, double sigma, double epsi2, const double *vars, const double *z, long Nvars, double *out,
+                        double *L_out);
+int orc_mh_accept(double logL_prop, double logPost_prop, double logPost_cur, double u, double *r_out);
+int orc_parallel_tempering(double *logL, double *logPrior, double *logPost, double *vars, double *params, int *moved, double *Pmove,
+                           const double *Tcoefs, long Nvars, long Nparams, int ind_A, double u, int literal_444, double *Pswap);
+int orc_learn_at(long i, const long *Nt_learn, const long *periods_learn, long n_periods);
+void orc_generate_model(const orc_sampler_star *S, const double *params, double Tcoef, double init_logL, double *model_scratch, double *logL,
+                        double *logPr, double *logPost);
+int orc_sampler_iteration(const orc_sampler_star *S, long i, int learn, int do_swap, int ind_A, double u_swap, int literal_444, const double *z,
+                          const double *u_mh, double *params, double *vars, double *logL, double *logPrior, double *logPost, int *moved,
+                          double *Pmove, double *mu, double *covarmat, double *sigma, int *swapped, double *prop_vars, double *prop_stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ MODEL_MS_GLOBAL_A1ETAA3_CLASSIC, MODEL_MS_LOCAL_BASIC, MODEL_MS_GLOBAL_AJ = 3, 1
 MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4 = 27   # constant-width variant of 25, same path
 MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4 = 25  # batched device path only (tamcmc_hip_loglike_params_batch): needs the ARMM pre-step
 PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_DIRECT = 0, 1, 2
-OPT_PRECISION, OPT_TIMING, OPT_BINS_PER_THREAD, OPT_WORKGROUP, OPT_FD_WINDOWED = 1, 2, 3, 4, 5
+OPT_PRECISION, OPT_TIMING, OPT_BINS_PER_THREAD, OPT_WORKGROUP, OPT_FD_WINDOWED, OPT_STEP_SCHEME, OPT_ARMM_DENSE_SCAN = 1, 2, 3, 4, 5, 6, 7
 
 
 class Multiplet(C.Structure):

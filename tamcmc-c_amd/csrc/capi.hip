@@ -85,6 +85,11 @@ int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
         c->geom_user_set = true;
         return TAMCMC_OK;
     case TAMCMC_OPT_FD_WINDOWED: c->fd_windowed = value ? 1 : 0; return TAMCMC_OK;
+    case TAMCMC_OPT_STEP_SCHEME:
+        if (value != 0 && value != 1) return TAMCMC_ERR_BAD_ARG;
+        c->step_scheme = (int)value;
+        return TAMCMC_OK;
+    case TAMCMC_OPT_ARMM_DENSE_SCAN: c->armm_dense = value ? 1 : 0; return TAMCMC_OK;
     case TAMCMC_OPT_WORKGROUP:  // sets the workgroup size AND its default bins per thread
         if (value != 64 && value != 256) return TAMCMC_ERR_BAD_ARG;
         c->wgs = (int)value;
@@ -138,14 +143,16 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     a.nnoise = (const int32_t *)(c->d_stage.p + L.off_nn);
     a.partials = c->d_part.p;
     a.model = model ? c->d_model.p : nullptr;
-    if (const char *ep = getenv("TAMCMC_PROBE_SKIP")) {  // timing tool only (tools/phase_probe.py): say so, loudly, once
+#ifdef TAMCMC_PROBE  // probe build only (tools/phase_probe.py)
+    if (const char *ep = getenv("TAMCMC_PROBE_SKIP")) {
         a.probe = atoi(ep);
         static bool warned = false;
         if (a.probe && !warned) {
             warned = true;
-            fprintf(stderr, "tamcmc_hip: TAMCMC_PROBE_SKIP=%d skips kernel phases -- the log-likelihoods of this process are WRONG (timing probe only)\n", a.probe);
+            fprintf(stderr, "tamcmc_hip (PROBE BUILD): TAMCMC_PROBE_SKIP=%d skips kernel phases -- the log-likelihoods of this process are WRONG\n", a.probe);
         }
     }
+#endif
     if (device_tables) a.tile_rot = tile_rot;
     else {
         const int32_t *pairs = (const int32_t *)(c->h_stage.p + L.off_pairs);

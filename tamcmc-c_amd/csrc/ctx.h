@@ -65,6 +65,8 @@ struct tamcmc_hip_ctx {
     int K = 4;      // bins per thread: tile = wgs*K bins
     bool geom_user_set = false;
     int fd_windowed = 1;  // FAST modes: finite differences through delta tables (changed multiplets on their windows only)
+    int step_scheme = 0;  // device sampler: 0 = fused step where possible, 1 = lockstep kernels only
+    int armm_dense = 0;   // red-giant pre-step: 1 = dense grid walk
     // resident spectrum
     int64_t Nx = 0;
     std::vector<double> hx;  // host copy of x (table builders need x[0], x[Nx-1], step)

@@ -16,6 +16,7 @@ namespace tamcmc {
 struct DevSamplerArgs {
     ModelDesc desc;       // model_id, prior_class, Np, per, stride, Nx, grid, plength/priors/extra/poly pointers
     int C, Nv, ntiles, chol_in_lds;
+    int swap_rule;        // 1: chain B's stored logPosterior after a swap as MALA.cpp:433,444 execute it
     long pl;              // likelihood_params truncated to long (likelihoods.h:14)
     long dN_mixing;
     uint64_t seed;
@@ -27,7 +28,6 @@ struct DevSamplerArgs {
     double *vars_prop, *params_prop, *logPr_prop;
     int *status_prop, *moved;
     double *Pmove;
-    long *dbg;            // optional phase stamps (TAMCMC_DEBUG_STAMPS=1)
     long *counters;       // [0] iteration, [1] accepted moves of chain 0, [2] swap attempts, [3] swaps accepted
     // proposal law
     double *LT, *cov, *mu, *sigma;   // LT = transposed Cholesky factor of (cov+eps2)*sigma
@@ -37,15 +37,10 @@ struct DevSamplerArgs {
     int *pairs, *nh, *nn;
     double *noise;
     double *partials;
-    double *bg;           // [C*D x ntiles x 8] background series per (slot, tile), FAST far field only (else nullptr)
+    double *bg;           // [C x ntiles x 8] background series per (slot, tile), FAST far field only (else nullptr)
     int tile_bins;
     // records
     double *samples, *stats;
-    // speculative rounds (k_spec): D candidate slots per chain; per-chain progress, parity-doubled like the chain state
-    int D;
-    long *sp_done;   // [2][C] iterations whose MH test is done
-    int *sp_nprop;   // [2][C] candidates proposed by the last round
-    int *sp_phase;   // [2][C] 1 = waits for its partner to resolve the swap of iteration sp_done-1
 };
 #endif
 
@@ -57,7 +52,8 @@ struct DevSamplerInit {
     uint64_t seed;
     long dN_mixing;
     double c0, epsilon1, epsi2, A1, target_acceptance;
-    int chain_groups = 0;  // 0 = default (TAMCMC_CHAIN_GROUPS, else 2 from 8 chains on)
+    int chain_groups = 0;  // 0 = default (2 from 8 chains on): stream groups of the lockstep scheme
+    int swap_rule = 0;     // tamcmc_sampler_config.swap_rule
 };
 
 class DevSampler {

@@ -1,22 +1,29 @@
 // dev_sampler.hip -- device-resident MCMC iteration (sampler-side algebra on the device).
 //
-// The host-driven loop (host_mala.cpp) spends ~3/4 of a step on the host (proposal, priors, table build, copies,
-// one sync per step).  Here one MCMC iteration of ALL tempered chains is TWO kernels on the context's stream, with no
-// host round trip and no copy in between:
-//   k_iterate  (one workgroup per chain)
-//      (0) settles the previous iteration: per-chain partial sums -> tempered logL, MH test (MALA.cpp:490-551),
-//          adjacent-pair parallel-tempering swap (MALA.cpp:397-461), sample/stat record (the outputs.cpp buffers),
-//          in learning phases the Robbins-Monro update of mu, Sigma, sigma (MALA.cpp:296-319) and the Cholesky
-//          factor of (Sigma+eps2 I) sigma (MALA.cpp:348-350);
-//      (1) proposes the next one: z ~ N(0,I) (Philox, same streams as the host engine), x' = x + L z
-//          (MALA.cpp:339-369), params' (model_def.cpp:484-492), log-prior with its terms spread over the lanes
-//          (priors_calc.cpp), params' -> multiplet table + noise row (models.cpp unpackers) written straight into
-//          the likelihood kernel's input block.
-//   k_loglike  (kernels.hip)  the hot kernel, unchanged.
-// All per-iteration state is double-buffered by parity: a workgroup reads parity P (any chain) and writes parity P^1
-// (its own chain only), so the swap needs no inter-workgroup synchronisation: the two workgroups of a swap pair
-// both recompute both MH tests from the same inputs and reach the same decision.
-// The host only enqueues launches and fetches the recorded samples once per run() call.
+// The host-driven loop (host_mala.cpp) spends ~3/4 of a step on the host (proposal, priors, table build, copies, one sync per
+// step).  Here the whole iteration of ALL tempered chains runs on the GPU; the host only enqueues launches and fetches the recorded
+// samples once per run() call.  Two launch schemes, same chains bit for bit (same Philox streams, same arithmetic, same orders):
+//
+// (A) FUSED STEP, one launch per iteration (k_step) -- used for every stretch of iterations WITHOUT adaptation (the bulk of a run:
+//     the reference learns in [Nt_learn[0], Nt_learn[last]) only, config_default.cfg:17-18).  Launch i holds two kinds of 64-lane
+//     workgroups:
+//       * likelihood tiles of iteration i (loglike_tile.h, the hot kernel's body): chain m's proposal of iteration i is table slot
+//         slot[m], chosen by the previous launch.  The LAST tile of a chain to finish (atomic ticket) settles the chain: fixed-order
+//         sum of the per-tile partials -> tempered logL -> MH test (MALA.cpp:490-551); for the two chains of the swap pair the second
+//         one to finish resolves the parallel-tempering swap (MALA.cpp:397-461); the settled state, the sample/stat record and the
+//         slot of the chain's NEXT proposal are written for launch i+1.
+//       * branch-ahead candidates of iteration i+1, built WHILE the tiles run: the proposal of i+1 is x + L z(i+1) where x is one of
+//         a few known vectors -- the chain's current position (test i rejects) or its proposal of i (accepts), and for the swap pair
+//         also the partner's two -- so all 2C+4 candidates (prior, table rows, background series) are prepared in advance by four
+//         single-wave roles each (prior | rows | background tiles, two halves).  Nothing but k_loglike's tiles is left on the
+//         critical path: an iteration costs one launch of ~C x ntiles tiles plus a short settle tail.
+// (B) LOCKSTEP, two kernels per iteration and chain group (k_iterate, k_loglike) -- used where the proposal law is adapted after
+//     every test (the next proposal needs the new Cholesky factor, so it cannot be prepared ahead):
+//       k_iterate (one workgroup per chain) settles iteration it-1 (MH test, swap, record, Robbins-Monro update MALA.cpp:296-319,
+//       Cholesky of (Sigma+eps2 I) sigma MALA.cpp:348-350) and proposes iteration it; k_loglike evaluates.
+// All per-iteration state is double-buffered by parity: a workgroup reads parity P and writes parity P^1, so the swap needs no
+// inter-workgroup synchronisation inside (B) and a launch never overwrites what it still reads in (A).  Both schemes keep the
+// chains' state in the same arrays; a stretch hands over to the next with the parity only.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -29,6 +36,7 @@
 #include "ctx.h"
 #include "dev_sampler.h"
 #include "kernels.h"
+#include "loglike_tile.h"
 #include "dev_unpack.h"
 #include "mode_tables.h"
 #include "rng.h"
@@ -44,13 +52,42 @@ __global__ void k_fill_poly(mt::PolyTab *t) {
 constexpr int TB = 256;  // threads of k_iterate (one workgroup per chain)
 
 // Outcome of the Metropolis-Hastings test of chain j for the pending iteration (MALA.cpp:490-551): the values the
-// chain holds AFTER the test.  Computed by a whole workgroup; every workgroup that needs chain j's outcome (the chain's
-// own workgroup and, in a swap step, its partner's) recomputes it from the same inputs -> identical results.
+// chain holds AFTER the test.
 struct AcceptOut {
     int acc;
     double r, logL, logPr, logPost;
 };
 
+// MALA.cpp:490-551 for one chain, by ONE lane: S = sum of the chain's per-tile partials, (logPr, status) = the proposal's prior and
+// table status, logPost_cur / logL_cur / logPr_cur = what the chain holds.  The same statement sequence serves both launch schemes.
+__device__ __forceinline__ AcceptOut mh_outcome(const DevSamplerArgs &a, int j, long itp, double S, double logPr, int status, double logL_cur,
+                                                double logPr_cur, double logPost_cur) {
+    double logL = (-(double)a.pl * S) / a.Tcoefs[j];  // call_likelihood, model_def.cpp:399-401
+    double logPost;
+    if (status != TAMCMC_OK) logL = NAN;
+    if (logPr == -INFINITY || isnan(logPr)) { logL = a.init_logL[j]; logPost = -INFINITY; }  // model_def.cpp:476-480
+    else logPost = logL + logPr;
+    double u, u1;
+    rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)j, (uint64_t)itp, 0, u, u1);
+    double r;
+    if (!isnan(logL)) {
+        if (logPost == -INFINITY) r = 0.;
+        else {
+            const double e = exp(logPost - logPost_cur);
+            r = fmin(1.0, e);
+            if (isnan(r)) r = 0.;
+        }
+    } else r = 0.;
+    AcceptOut o;
+    o.acc = (u <= r) ? 1 : 0;
+    o.r = r;
+    if (o.acc) { o.logL = logL; o.logPr = logPr; o.logPost = logPost; }
+    else { o.logL = logL_cur; o.logPr = logPr_cur; o.logPost = logPost_cur; }
+    return o;
+}
+
+// (B): computed by a whole 256-thread workgroup; every workgroup that needs chain j's outcome (the chain's own workgroup and, in a
+// swap step, its partner's) recomputes it from the same inputs -> identical results.
 __device__ void accept_result(const DevSamplerArgs &a, int j, long itp, int P, double *s_red, AcceptOut *s_out) {
     const int tid = threadIdx.x;
     // same reduction order as k_finalize (kernels.hip): strided per-thread sums, shuffle tree, waves in order
@@ -72,33 +109,33 @@ __device__ void accept_result(const DevSamplerArgs &a, int j, long itp, int P, d
     if (tid == 0) {
         double t1 = s_red[0], t2 = s_red[1];
         for (int w = 1; w < TB / 64; w++) { t1 = t1 + s_red[2 * w]; t2 = t2 + s_red[2 * w + 1]; }
-        const double S = t1 + t2;
         const int C = a.C;
-        double logL = (-(double)a.pl * S) / a.Tcoefs[j];  // call_likelihood, model_def.cpp:399-401
-        const double logPr = a.logPr_prop[P * C + j];
-        double logPost;
-        if (a.status_prop[P * C + j] != TAMCMC_OK) logL = NAN;
-        if (logPr == -INFINITY || isnan(logPr)) { logL = a.init_logL[j]; logPost = -INFINITY; }  // model_def.cpp:476-480
-        else logPost = logL + logPr;
-        double u, u1;
-        rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)j, (uint64_t)itp, 0, u, u1);
-        double r;
-        if (!isnan(logL)) {
-            if (logPost == -INFINITY) r = 0.;
-            else {
-                const double e = exp(logPost - a.logPost_cur[P * C + j]);
-                r = fmin(1.0, e);
-                if (isnan(r)) r = 0.;
-            }
-        } else r = 0.;
-        AcceptOut o;
-        o.acc = (u <= r) ? 1 : 0;
-        o.r = r;
-        if (o.acc) { o.logL = logL; o.logPr = logPr; o.logPost = logPost; }
-        else { o.logL = a.logL_cur[P * C + j]; o.logPr = a.logPr_cur[P * C + j]; o.logPost = a.logPost_cur[P * C + j]; }
-        *s_out = o;
+        *s_out = mh_outcome(a, j, itp, t1 + t2, a.logPr_prop[P * C + j], a.status_prop[P * C + j], a.logL_cur[P * C + j], a.logPr_cur[P * C + j],
+                            a.logPost_cur[P * C + j]);
     }
     __syncthreads();
+}
+
+// (A): the same sum by ONE wave, in k_finalize's order: 256 strided per-thread sums (four per lane here), shuffle tree per 64, the
+// four in order.  Every lane returns the total.
+__device__ __forceinline__ double wave_partial_sum(const double *base, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    double t1 = 0, t2 = 0;
+    for (int q = 0; q < TB / 64; q++) {
+        double s1 = 0, s2 = 0;
+        for (int t = q * 64 + lane; t < ntiles; t += TB) {
+            s1 = s1 + base[2 * t];
+            s2 = s2 + base[2 * t + 1];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s1 = s1 + __shfl_down(s1, off, 64);
+            s2 = s2 + __shfl_down(s2, off, 64);
+        }
+        if (q == 0) { t1 = s1; t2 = s2; }
+        else { t1 = t1 + s1; t2 = t2 + s2; }
+    }
+    return __shfl(t1 + t2, 0, 64);
 }
 
 // Robbins-Monro adaptation of chain m's proposal law (MALA.cpp:296-319) and Cholesky of (Sigma+eps2 I) sigma
@@ -180,7 +217,7 @@ __device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const doub
 
 // z ~ N(0, I) of (chain, iteration) into LDS (ends without a barrier) and row i of L z (MALA.cpp:348-355)
 __device__ __forceinline__ void normals_into(const DevSamplerArgs &a, int chain, long it, double *s_z) {
-    for (int k2 = threadIdx.x; 2 * k2 < a.Nv; k2 += TB) {
+    for (int k2 = threadIdx.x; 2 * k2 < a.Nv; k2 += (int)blockDim.x) {
         double z0, z1;
         rng_normal2(a.seed, RNG_PROPOSAL, (uint32_t)chain, (uint64_t)it, (uint32_t)k2, z0, z1);
         s_z[2 * k2] = z0;
@@ -196,12 +233,10 @@ __device__ __forceinline__ double Lz_row(const DevSamplerArgs &a, int chain, int
 
 // Proposal of iteration `it` for `chain` from the state in LDS (s_vars/s_params): x' = x + L z (MALA.cpp:348-355), L =
 // chol((Sigma+eps2) sigma) stored transposed, same Philox streams as the host engine; log-prior; params' -> multiplet table
-// written into slot `slot` of the likelihood kernel's input block.  Ends without a barrier.
+// written into slot `slot` of the likelihood kernel's input block.  Ends without a barrier.  (B): 256 threads.
 __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int chain, long it, int slot, double *pv, double *pp,
-                               double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, long *dbg,
-                               const double *lz = nullptr) {
+                               double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, const double *lz = nullptr) {
     const int Np = a.desc.Np, Nv = a.Nv, tid = threadIdx.x;
-#define PSTAMP(k) do { if (dbg && tid == 0) dbg[k] = (long)wall_clock64(); } while (0)
     if (!lz) normals_into(a, chain, it, s_z);
     unpack_begin(a.desc, U);
     for (int i = tid; i < Nv; i += TB) {  // lane i owns row i: reads s_vars[i] only, every s_z[k]
@@ -211,7 +246,6 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
         pv[i] = v;
     }
     __syncthreads();
-    PSTAMP(2);
     for (int k = tid; k < Nv; k += TB) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
     __syncthreads();
     for (int i = tid; i < Np; i += TB) pp[i] = s_params[i];
@@ -221,19 +255,46 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
     T.mults = a.mults; T.pairs = a.pairs; T.nh = a.nh; T.nn = a.nn; T.noise = a.noise;
     T.bg = a.bg; T.ntiles = a.ntiles; T.tile_bins = a.tile_bins;
     // four roles beside each other (dev_unpack.h): prior terms + background tiles | table rows | shared scalars + m-visibilities
-    const double logPr = wg_log_prior(a.desc, s_params, U, true, dbg, true, &T, slot);
-    PSTAMP(4);
+    const double logPr = wg_log_prior(a.desc, s_params, U, true, true, &T, slot);
     const bool live = (logPr != -INFINITY) && !isnan(logPr);  // model_def.cpp:472,476-480
-    wg_unpack(a.desc, s_params, U, slot, T, live, dbg, true, true);
+    wg_unpack(a.desc, s_params, U, slot, T, live, true, true);
     if (tid == 0) {
         *logPr_out = logPr;
         *status_out = *U.status;
     }
-    PSTAMP(6);
-#undef PSTAMP
 }
 
-// ONE kernel per MCMC iteration besides the likelihood kernel.  Workgroup m:
+__device__ __forceinline__ bool is_swap_iter(const DevSamplerArgs &a, long i) {
+    return a.dN_mixing > 0 && (i % a.dN_mixing == 0) && i != 0 && a.C > 1;
+}
+__device__ __forceinline__ int swap_first(const DevSamplerArgs &a, long i, double *u_out) {  // MALA.cpp:397-405
+    double u, u2;
+    rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)i, 0, u, u2);
+    int A = (int)(u2 * (double)(a.C - 1));
+    if (A > a.C - 2) A = a.C - 2;
+    if (u_out) *u_out = u;
+    return A;
+}
+
+// Parallel tempering (MALA.cpp:397-461) on the pair's outcomes AFTER their MH tests: does the pair swap, and what does each side
+// then hold as tempered logL / prior / posterior.  oA, oB are updated in place; returns 1 when swapped.
+__device__ __forceinline__ int resolve_swap(const DevSamplerArgs &a, int A, double u, AcceptOut &oA, AcceptOut &oB) {
+    const int B = A + 1;
+    const double LA = oA.logL, LB = oB.logL;
+    const double LA_TB = LA * a.Tcoefs[A] / a.Tcoefs[B];
+    const double LB_TA = LB * a.Tcoefs[B] / a.Tcoefs[A];
+    const double e = exp(LA_TB + LB_TA - LA - LB);
+    const double rT = fmin(1.0, e);
+    if (!(u <= rT)) return 0;
+    const double prA = oA.logPr, prB = oB.logPr;
+    oA.logL = LB_TA; oA.logPr = prB; oA.logPost = LB_TA + prB;      // A <- B, re-tempered (MALA.cpp:431-435)
+    // swap_rule 1 (MALA.cpp:433,444 as executed): B's stored posterior carries B's own old prior
+    oB.logL = LA_TB; oB.logPr = prA; oB.logPost = LA_TB + (a.swap_rule == 1 ? prB : prA);
+    return 1;
+}
+
+// ===============================================================================================================
+// (B) LOCKSTEP.  ONE kernel per MCMC iteration besides the likelihood kernel.  Workgroup m:
 //   (0) settles the pending iteration it-1 for chain m: MH test (own chain; the swap partner's too when chain m is in the
 //       swap pair), adjacent-pair parallel-tempering swap, writes the chain's new current state into the OTHER parity
 //       buffer (no workgroup ever writes what another one reads), records the sample, adapts the proposal law;
@@ -265,8 +326,6 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
 
     const int m = blockIdx.x + c_off, tid = threadIdx.x;  // c_off: first chain of this launch's chain group
     const int Q = P ^ 1;
-#define STAMP(k) do { if (PROPOSE && a.dbg && m == 0 && tid == 0) a.dbg[k] = (long)wall_clock64(); } while (0)
-    STAMP(0);
     const double *curv = a.vars_cur + (size_t)P * C * Nv, *curp = a.params_cur + (size_t)P * C * Np;
     const double *prpv = a.vars_prop + (size_t)P * C * Nv, *prpp = a.params_prop + (size_t)P * C * Np;
     double *newv = a.vars_cur + (size_t)Q * C * Nv, *newp = a.params_cur + (size_t)Q * C * Np;
@@ -276,31 +335,18 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
         const long itp = it - 1;
         accept_result(a, m, itp, P, s_red, &s_own);
         int src = m;
-        double logL_new = s_own.logL, logPr_new = s_own.logPr, logPost_new = s_own.logPost;
+        AcceptOut mine = s_own;
         // parallel tempering (MALA.cpp:397-461): adjacent pair, tempered log-likelihoods after the MH tests
-        const bool swap_step = a.dN_mixing > 0 && (itp % a.dN_mixing == 0) && itp != 0 && C > 1;
-        if (swap_step) {
-            double u, u2;
-            rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)itp, 0, u, u2);
-            int A = (int)(u2 * (double)(C - 1));
-            if (A > C - 2) A = C - 2;
+        if (is_swap_iter(a, itp)) {
+            double u;
+            const int A = swap_first(a, itp, &u);
             const int B = A + 1;
             if (m == A || m == B) {  // workgroup-uniform branch
                 const int partner = (m == A) ? B : A;
                 accept_result(a, partner, itp, P, s_red, &s_partner);
-                const double LA = (m == A) ? s_own.logL : s_partner.logL;
-                const double LB = (m == A) ? s_partner.logL : s_own.logL;
-                const double LA_TB = LA * a.Tcoefs[A] / a.Tcoefs[B];
-                const double LB_TA = LB * a.Tcoefs[B] / a.Tcoefs[A];
-                const double e = exp(LA_TB + LB_TA - LA - LB);
-                const double rT = fmin(1.0, e);
-                const bool swapped = (u <= rT);
-                if (swapped) {
-                    src = partner;
-                    logPr_new = s_partner.logPr;
-                    logL_new = (m == A) ? LB_TA : LA_TB;  // re-tempered value of the partner's likelihood
-                    logPost_new = logL_new + logPr_new;
-                }
+                AcceptOut oA = (m == A) ? s_own : s_partner, oB = (m == A) ? s_partner : s_own;
+                const int swapped = resolve_swap(a, A, u, oA, oB);
+                if (swapped) { src = partner; mine = (m == A) ? oA : oB; }
                 if (m == A && tid == 0) {  // (chain groups: launches of different iterations may overlap)
                     atomicAdd((unsigned long long *)&a.counters[2], 1ull);
                     if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
@@ -317,9 +363,9 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
             for (int i = tid; i < Nv; i += TB) s_z[i] = ov[i];
         }
         if (tid == 0) {
-            a.logL_cur[Q * C + m] = logL_new;
-            a.logPr_cur[Q * C + m] = logPr_new;
-            a.logPost_cur[Q * C + m] = logPost_new;
+            a.logL_cur[Q * C + m] = mine.logL;
+            a.logPr_cur[Q * C + m] = mine.logPr;
+            a.logPost_cur[Q * C + m] = mine.logPost;
             // a swap exchanges the pair's moved / Pmove entries too (MALA.cpp:425-446): what is recorded is the partner's
             a.moved[m] = (src == m) ? s_own.acc : s_partner.acc;
             a.Pmove[m] = (src == m) ? s_own.r : s_partner.r;
@@ -327,7 +373,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
             if (m == 0) a.counters[0] = it;
             if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
                 double *r = a.stats + ((size_t)rec * C + m) * 3;
-                r[0] = logL_new; r[1] = logPr_new; r[2] = logPost_new;
+                r[0] = mine.logL; r[1] = mine.logPr; r[2] = mine.logPost;
             }
         }
         __syncthreads();
@@ -346,267 +392,262 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
             a.logPost_cur[Q * C + m] = a.logPost_cur[P * C + m];
         }
     }
-    STAMP(1);
     if (!PROPOSE) return;
     __syncthreads();
 
     // ------------------------------------------------------------------ (1) propose iteration `it`
     propose_common(a, U, m, it, m, a.vars_prop + (size_t)Q * C * Nv + (size_t)m * Nv, a.params_prop + (size_t)Q * C * Np + (size_t)m * Np,
-                   a.logPr_prop + Q * C + m, a.status_prop + Q * C + m, s_vars, s_params, s_z, (a.dbg && m == 0) ? a.dbg : nullptr,
+                   a.logPr_prop + Q * C + m, a.status_prop + Q * C + m, s_vars, s_params, s_z,
                    (pre_flags & 1) ? a.lz + ((size_t)(it & 1) * C + m) * Nv : nullptr);
-#undef STAMP
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Speculative rounds for stretches WITHOUT adaptation (the proposal law is frozen, e.g. the Acquire phase).
-// A Metropolis-Hastings chain rejects ~3 proposals out of 4; when iteration i is rejected, the proposal of i+1 is
-// x + L z_{i+1} from the SAME x.  A round therefore evaluates, per chain, the candidates of iterations d, d+1, .., d+D-1
-// all built on the chain's current x; the next round tests them in order and consumes iterations up to and including the
-// first acceptance (later candidates are discarded).  Every random number is addressed by (chain, iteration), so each
-// chain follows exactly the trajectory of the one-iteration-per-round engine -- the chains merely stop advancing in
-// lockstep.  Parallel-tempering swaps (iteration s, pair A_s) are the only coupling: a chain of the pair proposes no
-// candidate beyond s, and after its MH test of s it waits (phase 1) until its partner has also tested s; both
-// workgroups then resolve the swap from the same inputs.
-struct SpecOut {
-    long done;                     // iterations whose MH test is done, after this round's tests
-    int phase;                     // 1 = waiting for the partner at the swap of iteration done-1
-    int src_chain, src_cand;       // where the chain's state vector lives (parity P): cand -1 = src_chain's current vector
-    int n_rec, acc_last, swap_last;  // iterations consumed by this round's tests; was the last one accepted; is it a swap step of this chain
-    int resolved, swapped;
-    int nprop_new;
-    double r_last;
-    double logL0, logPr0, logPost0;  // before this round's tests
-    double logL, logPr, logPost;     // after the tests (and after the swap once resolved)
+// ===============================================================================================================
+// (A) FUSED STEP.
+struct FusedArgs {
+    int NS;                // candidate slots per iteration: 2C + 4
+    // candidates of the iteration with parity q: [2][NS]...
+    double *cand_vars, *cand_params, *cand_logPr;
+    int *cand_stP, *cand_stR;          // status of the prior role / the rows role
+    tamcmc_multiplet *mults;           // [2][NS][per]
+    int *pairs, *nh, *nn;              // [2][2 NS], [2][NS], [2][NS]
+    double *noise;                     // [2][NS][stride]
+    double *bg;                        // [2][NS][ntiles][8] or nullptr
+    int *slot;                         // [2][C]   table slot of chain m's proposal at the iteration of that parity
+    unsigned *ticket;                  // [2][C]   tiles of chain m that have delivered their partial sums
+    unsigned *pair_ticket;             // [2]      chains of the swap pair that have done their MH test
+    AcceptOut *acc;                    // [2][C]   MH outcome of chain m (read by the partner that resolves the swap)
 };
 
-__device__ __forceinline__ bool is_swap_iter(const DevSamplerArgs &a, long i) {
-    return a.dN_mixing > 0 && (i % a.dN_mixing == 0) && i != 0 && a.C > 1;
-}
-__device__ __forceinline__ int swap_first(const DevSamplerArgs &a, long i, double *u_out) {  // MALA.cpp:397-405
-    double u, u2;
-    rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)i, 0, u, u2);
-    int A = (int)(u2 * (double)(a.C - 1));
-    if (A > a.C - 2) A = a.C - 2;
-    if (u_out) *u_out = u;
-    return A;
-}
-__device__ __forceinline__ bool in_swap_pair(const DevSamplerArgs &a, int c, long i) {
-    if (!is_swap_iter(a, i)) return false;
-    const int A = swap_first(a, i, nullptr);
-    return c == A || c == A + 1;
-}
+constexpr int ST_L = 1, ST_BR = 2, ST_ENTRY = 4;
 
-// Sums of the per-tile partials of chain c's candidates (wave w -> candidate w), in k_finalize's order: 256 strided
-// per-thread sums (four per lane here), shuffle tree per 64, the four in order.  No barrier inside.
-__device__ void spec_sums(const DevSamplerArgs &a, int c, int np, double *s_S) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (w >= np) return;  // wave-uniform
-    const double *base = a.partials + (size_t)(c * a.D + w) * a.ntiles * 2;
-    double t1 = 0, t2 = 0;
-    for (int q = 0; q < TB / 64; q++) {
-        double s1 = 0, s2 = 0;
-        for (int t = q * 64 + lane; t < a.ntiles; t += TB) {
-            s1 = s1 + base[2 * t];
-            s2 = s2 + base[2 * t + 1];
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            s1 = s1 + __shfl_down(s1, off, 64);
-            s2 = s2 + __shfl_down(s2, off, 64);
-        }
-        if (q == 0) { t1 = s1; t2 = s2; }
-        else { t1 = t1 + s1; t2 = t2 + s2; }
+// Writes chain m's settled state for the next iteration: position = chain `src`'s post-test position (its own, or the swap partner's),
+// scalars from `o` (already re-tempered after a swap); records the sample; names the slot of chain m's next proposal.
+__device__ __forceinline__ void fused_finalize(const DevSamplerArgs &a, const FusedArgs &f, int m, int src, int src_acc, double src_r,
+                                               const AcceptOut &o, int next_slot, long it, int q, long rec) {
+    const int lane = threadIdx.x, C = a.C, Nv = a.Nv, Np = a.desc.Np, q1 = q ^ 1;
+    const double *sv, *sp;
+    if (src_acc) {
+        const int ps = f.slot[q * C + src] & 0xffff;
+        sv = f.cand_vars + ((size_t)q * f.NS + ps) * Nv;
+        sp = f.cand_params + ((size_t)q * f.NS + ps) * Np;
+    } else {
+        sv = a.vars_cur + ((size_t)q * C + src) * Nv;
+        sp = a.params_cur + ((size_t)q * C + src) * Np;
     }
-    if (lane == 0) s_S[w] = t1 + t2;
-}
-
-// thread 0: the MH tests of chain c's candidates, in order (same arithmetic as accept_result)
-__device__ void spec_tests(const DevSamplerArgs &a, int c, int P, int first, long it_a, const double *S, SpecOut &o) {
-    const int C = a.C, D = a.D;
-    long d = first ? it_a : a.sp_done[P * C + c];
-    const int np = first ? 0 : a.sp_nprop[P * C + c];
-    int ph = first ? 0 : a.sp_phase[P * C + c];
-    o.logL0 = a.logL_cur[P * C + c]; o.logPr0 = a.logPr_cur[P * C + c]; o.logPost0 = a.logPost_cur[P * C + c];
-    o.logL = o.logL0; o.logPr = o.logPr0; o.logPost = o.logPost0;
-    o.src_chain = c; o.src_cand = -1;
-    o.n_rec = 0; o.acc_last = 0; o.r_last = 0; o.resolved = 0; o.swapped = 0;
-    for (int k = 0; k < np; k++) {
-        const int slot = c * D + k;
-        double logL = (-(double)a.pl * S[k]) / a.Tcoefs[c];  // call_likelihood, model_def.cpp:399-401
-        const double logPr = a.logPr_prop[(size_t)P * C * D + slot];
-        double logPost;
-        if (a.status_prop[(size_t)P * C * D + slot] != TAMCMC_OK) logL = NAN;
-        if (logPr == -INFINITY || isnan(logPr)) { logL = a.init_logL[c]; logPost = -INFINITY; }  // model_def.cpp:476-480
-        else logPost = logL + logPr;
-        double u, u1;
-        rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)c, (uint64_t)d, 0, u, u1);
-        double r;
-        if (!isnan(logL)) {
-            if (logPost == -INFINITY) r = 0.;
-            else {
-                const double e = exp(logPost - o.logPost0);
-                r = fmin(1.0, e);
-                if (isnan(r)) r = 0.;
-            }
-        } else r = 0.;
-        const int acc = (u <= r) ? 1 : 0;
-        o.n_rec++;
-        d++;
-        o.r_last = r;
-        o.acc_last = acc;
-        if (acc) {
-            o.src_cand = k;
-            o.logL = logL; o.logPr = logPr; o.logPost = logPost;
-            break;
+    double *dv = a.vars_cur + ((size_t)q1 * C + m) * Nv, *dp = a.params_cur + ((size_t)q1 * C + m) * Np;
+    double *rv = (a.samples && rec >= 0) ? a.samples + ((size_t)rec * C + m) * Nv : nullptr;  // update_buffer_params (MALA.cpp:710)
+    for (int i = lane; i < Nv; i += 64) { const double v = sv[i]; dv[i] = v; if (rv) rv[i] = v; }
+    for (int i = lane; i < Np; i += 64) dp[i] = sp[i];
+    if (lane == 0) {
+        a.logL_cur[q1 * C + m] = o.logL;
+        a.logPr_cur[q1 * C + m] = o.logPr;
+        a.logPost_cur[q1 * C + m] = o.logPost;
+        f.slot[q1 * C + m] = next_slot;
+        a.moved[m] = src_acc;     // a swap exchanges the pair's moved / Pmove entries too (MALA.cpp:425-446)
+        a.Pmove[m] = src_r;
+        if (m == 0 && src_acc) a.counters[1] += 1;
+        if (m == 0) a.counters[0] = it + 1;
+        if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
+            double *r = a.stats + ((size_t)rec * C + m) * 3;
+            r[0] = o.logL; r[1] = o.logPr; r[2] = o.logPost;
         }
     }
-    o.swap_last = (o.n_rec > 0 && in_swap_pair(a, c, d - 1)) ? 1 : 0;
-    if (o.swap_last) ph = 1;
-    o.done = d;
-    o.phase = ph;
 }
 
-__global__ void __launch_bounds__(TB) k_spec(const DevSamplerArgs a, const int P, const int first, const long it_a, const long it_b,
-                                            const long rec_base) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    const int Np = a.desc.Np, Nv = a.Nv, C = a.C, D = a.D;
-    double *s_params = (double *)s_raw;
+// Tail of the likelihood tiles of the fused step: every tile's wave calls it once its partial sums are written.
+struct SettleTail {
+    const DevSamplerArgs &a;
+    const FusedArgs &f;
+    long it, rec;
+    int q;
+    __device__ __forceinline__ void operator()(int m) const {
+        const int lane = threadIdx.x, C = a.C;
+        __threadfence();  // release: this tile's partial sums are visible device-wide before the ticket counts them
+        unsigned old = 0;
+        if (lane == 0) old = atomicAdd(&f.ticket[q * C + m], 1u);
+        old = __shfl(old, 0, 64);
+        if (old != (unsigned)(a.ntiles - 1)) return;  // not the chain's last tile (wave-uniform)
+        __threadfence();  // acquire: the other tiles' partial sums
+        // ---- the chain's MH test (MALA.cpp:490-551)
+        const double S = wave_partial_sum(a.partials + (size_t)m * a.ntiles * 2, a.ntiles);
+        const int ps = f.slot[q * C + m] & 0xffff;
+        AcceptOut o = {0, 0., 0., 0., 0.};
+        if (lane == 0) {
+            const int stP = f.cand_stP[q * f.NS + ps], stR = f.cand_stR[q * f.NS + ps];
+            o = mh_outcome(a, m, it, S, f.cand_logPr[q * f.NS + ps], stP != TAMCMC_OK ? stP : stR, a.logL_cur[q * C + m], a.logPr_cur[q * C + m],
+                           a.logPost_cur[q * C + m]);
+        }
+        o.acc = __shfl(o.acc, 0, 64); o.r = __shfl(o.r, 0, 64);
+        o.logL = __shfl(o.logL, 0, 64); o.logPr = __shfl(o.logPr, 0, 64); o.logPost = __shfl(o.logPost, 0, 64);
+        // ---- parallel tempering (MALA.cpp:397-461): the second chain of the pair to get here resolves the swap for both
+        int A = -1;
+        double u = 0;
+        if (is_swap_iter(a, it)) A = swap_first(a, it, &u);
+        if (m != A && m != A + 1) {
+            fused_finalize(a, f, m, m, o.acc, o.r, o, 2 * m + o.acc, it, q, rec);
+            return;
+        }
+        if (lane == 0) f.acc[q * C + m] = o;
+        __threadfence();
+        unsigned first = 0;
+        if (lane == 0) first = atomicAdd(&f.pair_ticket[q], 1u);
+        first = __shfl(first, 0, 64);
+        if (first == 0) return;  // the partner is still being evaluated: its last tile does the rest
+        __threadfence();
+        const int partner = (m == A) ? A + 1 : A;
+        AcceptOut op = {0, 0., 0., 0., 0.};
+        if (lane == 0) op = f.acc[q * C + partner];
+        op.acc = __shfl(op.acc, 0, 64); op.r = __shfl(op.r, 0, 64);
+        op.logL = __shfl(op.logL, 0, 64); op.logPr = __shfl(op.logPr, 0, 64); op.logPost = __shfl(op.logPost, 0, 64);
+        AcceptOut oA = (m == A) ? o : op, oB = (m == A) ? op : o;
+        const int accA = oA.acc, accB = oB.acc;
+        const double rA = oA.r, rB = oB.r;
+        const int swapped = resolve_swap(a, A, u, oA, oB);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&a.counters[2], 1ull);
+            if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
+        }
+        const int B = A + 1;
+        if (swapped) {  // each side continues from the other's post-test position: the extra candidate slots 2C .. 2C+3
+            fused_finalize(a, f, A, B, accB, rB, oA, 2 * C + accB, it, q, rec);
+            fused_finalize(a, f, B, A, accA, rA, oB, 2 * C + 2 + accA, it, q, rec);
+        } else {
+            fused_finalize(a, f, A, A, accA, rA, oA, 2 * A + accA, it, q, rec);
+            fused_finalize(a, f, B, B, accB, rB, oB, 2 * B + accB, it, q, rec);
+        }
+    }
+};
+
+// The three kinds of work on one candidate (see candidate_role); the proposal vector is in LDS.
+__device__ __attribute__((noinline)) void role_prior(const DevSamplerArgs &a, const FusedArgs &f, size_t gs, const double *s_vars,
+                                                     const double *s_params, const UnpackLds &U) {
+    const int Nv = a.Nv, Np = a.desc.Np, tid = threadIdx.x;
+    for (int i = tid; i < Nv; i += 64) f.cand_vars[gs * Nv + i] = s_vars[i];
+    for (int i = tid; i < Np; i += 64) f.cand_params[gs * Np + i] = s_params[i];
+    const double logPr = wave_log_prior(a.desc, s_params, U, TB - 128);  // the proposal kernel's 128 term lanes (dev_unpack.h)
+    if (tid == 0) { f.cand_logPr[gs] = logPr; f.cand_stP[gs] = *U.status; }
+}
+__device__ __forceinline__ TablePtrs candidate_tables(const DevSamplerArgs &a, const FusedArgs &f, int q_dst) {
+    TablePtrs T;
+    T.mults = f.mults + (size_t)q_dst * f.NS * a.desc.per; T.pairs = f.pairs + (size_t)q_dst * 2 * f.NS; T.nh = f.nh + (size_t)q_dst * f.NS;
+    T.nn = f.nn + (size_t)q_dst * f.NS; T.noise = f.noise + (size_t)q_dst * f.NS * a.desc.stride;
+    T.bg = nullptr; T.ntiles = a.ntiles; T.tile_bins = a.tile_bins;
+    return T;
+}
+__device__ __attribute__((noinline)) void role_rows(const DevSamplerArgs &a, const FusedArgs &f, int q_dst, int slot, size_t gs,
+                                                    const double *s_params, const UnpackLds &U) {
+    if (threadIdx.x == 0) mt::shared_scalars_base(a.desc.model_id, s_params, a.desc.plength, *U.S);
+    __syncthreads();
+    const TablePtrs T = candidate_tables(a, f, q_dst);
+    // the table is built whatever the prior says (this role does not know it): a vector outside a prior's support is rejected by
+    // the settle step before its likelihood is looked at (model_def.cpp:476-480), a table that cannot be built leaves an empty slot
+    wg_unpack(a.desc, s_params, U, slot, T, true, false, false, true);
+    if (threadIdx.x == 0) f.cand_stR[gs] = *U.status;
+}
+__device__ __attribute__((noinline)) void role_background(const DevSamplerArgs &a, const FusedArgs &f, int q_dst, int slot, int role,
+                                                          const double *s_params, const UnpackLds &U) {
+    if (!f.bg) return;
+    if (threadIdx.x == 0) mt::shared_scalars_base(a.desc.model_id, s_params, a.desc.plength, *U.S);
+    __syncthreads();
+    TablePtrs T = candidate_tables(a, f, q_dst);
+    T.bg = f.bg + (size_t)q_dst * f.NS * a.ntiles * bg::NH;
+    const int half = (a.ntiles + 1) / 2;
+    wg_bg_tiles(a.desc, s_params, U.S, slot, T, 0, 64, role == 2 ? 0 : half, role == 2 ? half : a.ntiles);
+}
+
+// One role of one candidate slot of iteration `itn`, by ONE wave.  Slot s < 2C: chain s/2, built on its current position (even) or
+// on its proposal of iteration itn-1 (odd); slots 2C..2C+3 (only when itn-1 swaps a pair A,B): chain A on B's two vectors, chain B on
+// A's two.  Roles: 0 = position + log-prior, 1 = table rows + noise row, 2 / 3 = background series of the lower / upper half of the
+// tiles.  Every role re-derives the proposal vector itself (no communication between the roles).
+__device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, long itn, int q_src, int q_dst, int slot, int role, bool entry,
+                               unsigned char *lds) {
+    const int C = a.C, Nv = a.Nv, Np = a.desc.Np, tid = threadIdx.x;
+    int m, src, on_prop;
+    if (slot < 2 * C) { m = slot >> 1; src = m; on_prop = slot & 1; }
+    else {
+        if (entry || !is_swap_iter(a, itn - 1)) return;
+        const int A = swap_first(a, itn - 1, nullptr), e = slot - 2 * C;
+        m = (e < 2) ? A : A + 1;
+        src = (e < 2) ? A + 1 : A;
+        on_prop = e & 1;
+    }
+    if (entry && on_prop) return;  // a stretch starts from settled chains: there is no pending proposal to build on
+    if (role == 0 && slot < 2 * C && !on_prop && tid == 0) {  // housekeeping for the launch that evaluates these candidates
+        f.ticket[q_dst * C + m] = 0u;
+        if (m == 0) f.pair_ticket[q_dst] = 0u;
+        if (entry) f.slot[q_dst * C + m] = 2 * m;
+    }
+    double *s_params = (double *)lds;
     double *s_vars = s_params + Np;
     double *s_z = s_vars + Nv;
     const UnpackLds U = carve_unpack_lds((unsigned char *)(s_z + Nv + 1));
-    __shared__ SpecOut s_me, s_pt;
-    __shared__ double s_S[4], s_Sp[4];
+    const double *bv, *bp;
+    if (on_prop) {
+        const int ps = f.slot[q_src * C + src] & 0xffff;
+        bv = f.cand_vars + ((size_t)q_src * f.NS + ps) * Nv;
+        bp = f.cand_params + ((size_t)q_src * f.NS + ps) * Np;
+    } else {
+        bv = a.vars_cur + ((size_t)q_src * C + src) * Nv;
+        bp = a.params_cur + ((size_t)q_src * C + src) * Np;
+    }
+    for (int i = tid; i < Nv; i += 64) s_vars[i] = bv[i];
+    for (int i = tid; i < Np; i += 64) s_params[i] = bp[i];
+    normals_into(a, m, itn, s_z);
+    unpack_begin(a.desc, U);  // (barrier)
+    for (int i = tid; i < Nv; i += 64) s_vars[i] = s_vars[i] + 0.0 + Lz_row(a, m, i, s_z);  // same expression as propose_common
+    __syncthreads();
+    for (int k = tid; k < Nv; k += 64) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
+    __syncthreads();
+    const size_t gs = (size_t)q_dst * f.NS + slot;
+    // (three separate functions: inlined side by side the roles' code raises the whole kernel's register allocation above the
+    // three-waves-per-SIMD budget of the tile path)
+    if (role == 0) role_prior(a, f, gs, s_vars, s_params, U);
+    else if (role == 1) role_rows(a, f, q_dst, slot, gs, s_params, U);
+    else role_background(a, f, q_dst, slot, role, s_params, U);
+}
 
-    const int c = blockIdx.x / D, j = blockIdx.x - c * D, tid = threadIdx.x;
-    const int Q = P ^ 1;
-    const size_t CD = (size_t)C * D;
+// Launch `it` of a fused stretch: [0, nbr) candidate roles of iteration it+1 (flags & ST_BR; at the entry of a stretch, ST_ENTRY:
+// of iteration `it` itself from the settled chains, and nothing else), then the likelihood tiles of iteration `it` (flags & ST_L).
+#define TAMCMC_STEP_BODY                                                                                                      \
+    __shared__ tile::TileLds<MODE, 64> lds;                                                                                  \
+    const int id = (int)blockIdx.x;                                                                                          \
+    if (id < nbr) {                                                                                                          \
+        if (flags & ST_ENTRY) candidate_role(a, f, it, q, q, id >> 2, id & 3, true, (unsigned char *)&lds);                  \
+        else candidate_role(a, f, it + 1, q, q ^ 1, id >> 2, id & 3, false, (unsigned char *)&lds);                          \
+        return;                                                                                                              \
+    }                                                                                                                        \
+    if (flags & ST_L) tile::loglike_tile<MODE, 64, K, false, false>(la, id - nbr, lds, SettleTail{a, f, it, rec, q});
+// The tile path of K <= 8 bins per lane fits 168 VGPRs = three waves per SIMD; the candidate roles (log-prior, series) would raise the
+// kernel's allocation above that, so the occupancy is pinned here (those roles may spill, they are off the critical path).
+template <int MODE, int K>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_step(const DevSamplerArgs a, const FusedArgs f, const LoglikeArgs la,
+                                                                                      const long it, const int q, const long rec, const int flags,
+                                                                                      const int nbr) {
+    TAMCMC_STEP_BODY
+}
+template <int MODE, int K>
+__global__ void __launch_bounds__(64) k_step_wide(const DevSamplerArgs a, const FusedArgs f, const LoglikeArgs la, const long it, const int q,
+                                                 const long rec, const int flags, const int nbr) {
+    TAMCMC_STEP_BODY
+}
+#undef TAMCMC_STEP_BODY
 
-    // ---- (0) this chain's MH tests
-    const int np = first ? 0 : a.sp_nprop[P * C + c];
-    spec_sums(a, c, np, s_S);
-    __syncthreads();
-    if (tid == 0) spec_tests(a, c, P, first, it_a, s_S, s_me);
-    __syncthreads();
-    // ---- (1) swap: both chains of the pair have tested iteration s -> resolve (each side recomputes the other's tests)
-    if (s_me.phase == 1) {  // workgroup-uniform
-        const long sidx = s_me.done - 1;
-        const int A = swap_first(a, sidx, nullptr);
-        const int partner = (c == A) ? A + 1 : A;
-        const int npp = first ? 0 : a.sp_nprop[P * C + partner];
-        spec_sums(a, partner, npp, s_Sp);
-        __syncthreads();
-        if (tid == 0) {
-            spec_tests(a, partner, P, first, it_a, s_Sp, s_pt);
-            if (s_pt.phase == 1 && s_pt.done == s_me.done) {
-                double u;
-                swap_first(a, sidx, &u);
-                const int B = A + 1;
-                const double LA = (c == A) ? s_me.logL : s_pt.logL;
-                const double LB = (c == A) ? s_pt.logL : s_me.logL;
-                const double LA_TB = LA * a.Tcoefs[A] / a.Tcoefs[B];
-                const double LB_TA = LB * a.Tcoefs[B] / a.Tcoefs[A];
-                const double e = exp(LA_TB + LB_TA - LA - LB);
-                const double rT = fmin(1.0, e);
-                const bool swapped = (u <= rT);
-                if (swapped) {
-                    s_me.src_chain = partner;
-                    s_me.src_cand = s_pt.src_cand;
-                    s_me.logPr = s_pt.logPr;
-                    s_me.logL = (c == A) ? LB_TA : LA_TB;  // re-tempered value of the partner's likelihood
-                    s_me.logPost = s_me.logL + s_me.logPr;
-                }
-                s_me.phase = 0;
-                s_me.resolved = 1;
-                s_me.swapped = swapped ? 1 : 0;
-                if (c == A && j == 0) {  // several pairs (of different iterations) may resolve in one round
-                    atomicAdd((unsigned long long *)&a.counters[2], 1ull);
-                    if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- (2) how many candidates the chain proposes now: none while it waits; none past the end of the stretch; none past a
-    //          swap step it takes part in
-    if (tid == 0) {
-        int n = 0;
-        if (s_me.phase == 0) {
-            for (int k = 0; k < D; k++) {
-                const long i = s_me.done + k;
-                if (i >= it_b) break;
-                n++;
-                if (in_swap_pair(a, c, i)) break;
-            }
-        }
-        s_me.nprop_new = n;
-    }
-    __syncthreads();
-    // ---- (3) the chain's state -> LDS (and, by the chain's first workgroup, -> the other parity buffer + records)
-    const double *curv = a.vars_cur + (size_t)P * C * Nv, *curp = a.params_cur + (size_t)P * C * Np;
-    const double *cndv = a.vars_prop + (size_t)P * CD * Nv, *cndp = a.params_prop + (size_t)P * CD * Np;
-    const int sc = s_me.src_chain, sk = s_me.src_cand;
-    const double *sv = (sk < 0) ? curv + (size_t)sc * Nv : cndv + ((size_t)sc * D + sk) * Nv;
-    const double *sp = (sk < 0) ? curp + (size_t)sc * Np : cndp + ((size_t)sc * D + sk) * Np;
-    for (int i = tid; i < Nv; i += TB) s_vars[i] = sv[i];
-    for (int i = tid; i < Np; i += TB) s_params[i] = sp[i];
-    __syncthreads();
-    if (j == 0) {
-        double *newv = a.vars_cur + (size_t)Q * C * Nv + (size_t)c * Nv, *newp = a.params_cur + (size_t)Q * C * Np + (size_t)c * Np;
-        for (int i = tid; i < Nv; i += TB) newv[i] = s_vars[i];
-        for (int i = tid; i < Np; i += TB) newp[i] = s_params[i];
-        // records (update_buffer_params / update_buffer_stat_criteria, MALA.cpp:708-710): rejected iterations hold the old
-        // state; the last tested iteration holds the new one when accepted; a swap step is recorded once the swap is resolved
-        const long d0 = s_me.done - s_me.n_rec;
-        const int deferred_now = s_me.swap_last;                        // the last tested iteration waits for the swap
-        const int last_new = (s_me.n_rec > 0 && (s_me.acc_last || deferred_now)) ? 1 : 0;
-        const int n_old = s_me.n_rec - last_new;
-        // final-state record: an accepted (non-swap) last iteration, or the swap step resolved in this round
-        const int rec_final = (s_me.n_rec > 0 && s_me.acc_last && !deferred_now) || s_me.resolved;
-        if (a.samples) {
-            const double *ov = curv + (size_t)c * Nv;
-            for (int t = 0; t < n_old; t++)
-                for (int i = tid; i < Nv; i += TB) a.samples[((size_t)(d0 + t - rec_base) * C + c) * Nv + i] = ov[i];
-            if (rec_final)
-                for (int i = tid; i < Nv; i += TB) a.samples[((size_t)(s_me.done - 1 - rec_base) * C + c) * Nv + i] = s_vars[i];
-        }
-        if (tid == 0) {
-            if (a.stats) {
-                for (int t = 0; t < n_old; t++) {
-                    double *r = a.stats + ((size_t)(d0 + t - rec_base) * C + c) * 3;
-                    r[0] = s_me.logL0; r[1] = s_me.logPr0; r[2] = s_me.logPost0;
-                }
-                if (rec_final) {
-                    double *r = a.stats + ((size_t)(s_me.done - 1 - rec_base) * C + c) * 3;
-                    r[0] = s_me.logL; r[1] = s_me.logPr; r[2] = s_me.logPost;
-                }
-            }
-            a.logL_cur[Q * C + c] = s_me.logL;
-            a.logPr_cur[Q * C + c] = s_me.logPr;
-            a.logPost_cur[Q * C + c] = s_me.logPost;
-            a.sp_done[Q * C + c] = s_me.done;
-            a.sp_nprop[Q * C + c] = s_me.nprop_new;
-            a.sp_phase[Q * C + c] = s_me.phase;
-            if (s_me.n_rec > 0) {
-                a.moved[c] = s_me.acc_last;
-                a.Pmove[c] = s_me.r_last;
-                if (c == 0 && s_me.acc_last) a.counters[1] += 1;
-            }
-            atomicAdd((unsigned long long *)&a.counters[4], (unsigned long long)s_me.nprop_new);  // candidates handed to the likelihood kernel
-        }
-    }
-    // ---- (4) candidate j: the proposal of iteration done+j, or an empty slot
-    const int slot = c * D + j;
-    if (j < s_me.nprop_new) {
-        propose_common(a, U, c, s_me.done + j, slot, a.vars_prop + ((size_t)Q * CD + slot) * Nv, a.params_prop + ((size_t)Q * CD + slot) * Np,
-                       a.logPr_prop + (size_t)Q * CD + slot, a.status_prop + (size_t)Q * CD + slot, s_vars, s_params, s_z,
-                       (a.dbg && c == 0 && j == 0) ? a.dbg : nullptr);
-    } else if (tid == 0) {
-        a.pairs[2 * slot] = slot * a.desc.per;
-        a.pairs[2 * slot + 1] = slot * a.desc.per;
-        a.nh[slot] = 0;
-        a.nn[slot] = 0;  // the likelihood kernel skips the slot
-    }
+template <int MODE>
+bool launch_step_k(int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la, long it, int q, long rec,
+                   int flags, int nbr) {
+    if (K == 4) hipLaunchKernelGGL((k_step<MODE, 4>), dim3(grid), dim3(64), 0, st, a, f, la, it, q, rec, flags, nbr);
+    else if (K == 8) hipLaunchKernelGGL((k_step<MODE, 8>), dim3(grid), dim3(64), 0, st, a, f, la, it, q, rec, flags, nbr);
+    else if (K == 16) hipLaunchKernelGGL((k_step_wide<MODE, 16>), dim3(grid), dim3(64), 0, st, a, f, la, it, q, rec, flags, nbr);
+    else return false;
+    return true;
+}
+hipError_t launch_step(int mode, int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la, long it,
+                       int q, long rec, int flags, int nbr) {
+    bool ok;
+    if (mode == TAMCMC_PRECISION_FAST) ok = launch_step_k<tile::M_FAST>(K, grid, st, a, f, la, it, q, rec, flags, nbr);
+    else if (mode == TAMCMC_PRECISION_FAST_DIRECT) ok = launch_step_k<tile::M_FAST_DIRECT>(K, grid, st, a, f, la, it, q, rec, flags, nbr);
+    else ok = launch_step_k<tile::M_STRICT>(K, grid, st, a, f, la, it, q, rec, flags, nbr);
+    return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -626,7 +667,10 @@ struct DevSampler::Impl {
     int parity = 0;  // which of the two state buffers holds the chains' current state
     // chain groups: the chains are split into G contiguous groups, each on its own stream, so that one group's k_iterate
     // overlaps the other groups' k_loglike (an iteration is a serial k_iterate -> k_loglike chain per group)
-    bool pre_lz = true;  // spare workgroups compute L z one iteration ahead (TAMCMC_PRE_LZ=0 disables)
+    bool pre_lz = true;  // (B): spare workgroups compute L z one iteration ahead while L is frozen
+    FusedArgs f{};       // (A): candidate slots, tickets
+    bool fused_ok = false;
+    int fused_mode = -1, fused_K = 0;  // the geometry the (A) buffers were sized for
     int tile_rot = 0;  // launch-order hint of k_loglike (first near-field tile of chain 0's initial table)
     std::vector<int32_t> h_plength;
     int G = 1;
@@ -692,17 +736,10 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     a.desc.Nx = (int)c->Nx;
     a.desc.x_first = c->hx[0]; a.desc.x_last = c->hx[(size_t)c->Nx - 1]; a.desc.step = c->hx[1] - c->hx[0];
     a.pl = (long)in.likelihood_params;
-    a.seed = in.seed; a.dN_mixing = in.dN_mixing;
+    a.seed = in.seed; a.dN_mixing = in.dN_mixing; a.swap_rule = in.swap_rule == 1 ? 1 : 0;
     a.c0 = in.c0; a.epsilon1 = in.epsilon1; a.epsi2 = in.epsi2; a.A1 = in.A1; a.target_acceptance = in.target_acceptance;
     const size_t C = (size_t)in.C, Np = (size_t)in.Np, Nv = (size_t)in.Nv;
-    {  // candidate slots per chain of the speculative rounds (1 = one iteration per round everywhere)
-        const char *ed = getenv("TAMCMC_SPEC_DEPTH");
-        int D = ed ? atoi(ed) : 1;  // measured on MI355X (C3, 20 chains): extra candidates cost ~1 us each, more than they save
-        if (D < 1) D = 1;
-        if (D > TB / 64) D = TB / 64;  // spec_sums: one wave per candidate
-        a.D = D;
-    }
-    const size_t CD = C * (size_t)a.D;
+    const size_t CD = C;
     hipStream_t st = c->stream;
     int *d_pl, *d_idx, *d_sw;
     double *d_pr, *d_ex, *d_T;
@@ -716,16 +753,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.vars_prop, 2 * CD * Nv)); DCHK(I.dalloc(&a.params_prop, 2 * CD * Np));
     DCHK(I.dalloc(&a.logL_cur, 2 * C)); DCHK(I.dalloc(&a.logPr_cur, 2 * C)); DCHK(I.dalloc(&a.logPost_cur, 2 * C));
     DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * CD)); DCHK(I.dalloc(&a.status_prop, 2 * CD));
-    DCHK(I.dalloc(&a.sp_done, 2 * C)); DCHK(I.dalloc(&a.sp_nprop, 2 * C)); DCHK(I.dalloc(&a.sp_phase, 2 * C));
     DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8));
-    a.dbg = nullptr;
-    if (const char *es = getenv("TAMCMC_DEBUG_STAMPS")) {
-        // 1: phase stamps of one workgroup per kernel; 2: also a (start, end) pair of EVERY k_loglike workgroup of chain group 0
-        const size_t n = 16 + 8 + 2 * CD * 4096;
-        DCHK(I.dalloc(&a.dbg, n));
-        DCHK(hipMemsetAsync(a.dbg, 0, n * sizeof(long), st));
-        if (atoi(es) == 2) { const long magic = 77; DCHK(hipMemcpyAsync(a.dbg + 8 + 7, &magic, sizeof(long), hipMemcpyHostToDevice, st)); }
-    }
     DCHK(I.dalloc(&a.lz, 2 * C * Nv)); DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, CD * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * CD)); DCHK(I.dalloc(&a.nh, CD)); DCHK(I.dalloc(&a.nn, CD));
     DCHK(I.dalloc(&a.noise, CD * (size_t)a.desc.stride));
@@ -742,7 +770,6 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
         DCHK(hipFuncSetAttribute((const void *)k_iterate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(I.lds_base + I.lds_adapt)));
         DCHK(hipFuncSetAttribute((const void *)k_iterate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(I.lds_base + I.lds_adapt)));
     }
-    if (I.lds_base > 64 * 1024) DCHK(hipFuncSetAttribute((const void *)k_spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_base));
     // polynomial tables Pslm/Qlm: computed ON the device (its own double arithmetic), read through a uniform pointer
     mt::PolyTab *d_tab;
     DCHK(I.dalloc(&d_tab, 1));
@@ -751,9 +778,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     a.desc.poly = d_tab;
     for (int i = 0; i < 64; i++) { DCHK(hipEventCreate(&I.ev[i][0])); DCHK(hipEventCreate(&I.ev[i][1])); I.n_ev = i + 1; }
     {
-        if (const char *ep = getenv("TAMCMC_PRE_LZ")) I.pre_lz = atoi(ep) != 0;
-        const char *eg = getenv("TAMCMC_CHAIN_GROUPS");
-        int G = in.chain_groups > 0 ? in.chain_groups : eg ? atoi(eg) : (in.C >= 8 ? 2 : 1);
+        int G = in.chain_groups > 0 ? in.chain_groups : (in.C >= 8 ? 2 : 1);
         if (G < 1) G = 1;
         if (G > 4) G = 4;
         if (G > in.C) G = in.C;
@@ -767,6 +792,23 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
             DCHK(hipEventCreateWithFlags(&I.ev_join[g], hipEventDisableTiming));
         }
         I.ev_made = true;
+    }
+    {  // (A) fused step: 2C+4 candidate slots per iteration parity, tickets, outcomes (tables are sized at the first run())
+        FusedArgs &f = I.f;
+        f.NS = 2 * in.C + 4;
+        const size_t NS = (size_t)f.NS;
+        DCHK(I.dalloc(&f.cand_vars, 2 * NS * Nv)); DCHK(I.dalloc(&f.cand_params, 2 * NS * Np)); DCHK(I.dalloc(&f.cand_logPr, 2 * NS));
+        DCHK(I.dalloc(&f.cand_stP, 2 * NS)); DCHK(I.dalloc(&f.cand_stR, 2 * NS));
+        DCHK(I.dalloc(&f.mults, 2 * NS * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&f.pairs, 4 * NS)); DCHK(I.dalloc(&f.nh, 2 * NS)); DCHK(I.dalloc(&f.nn, 2 * NS));
+        DCHK(I.dalloc(&f.noise, 2 * NS * (size_t)a.desc.stride));
+        DCHK(I.dalloc(&f.slot, 2 * C)); DCHK(I.dalloc(&f.ticket, 2 * C)); DCHK(I.dalloc(&f.pair_ticket, 2)); DCHK(I.dalloc(&f.acc, 2 * C));
+        DCHK(hipMemsetAsync(f.nn, 0, 2 * NS * sizeof(int), st));
+        DCHK(hipMemsetAsync(f.cand_stP, 0, 2 * NS * sizeof(int), st));
+        DCHK(hipMemsetAsync(f.cand_stR, 0, 2 * NS * sizeof(int), st));
+        f.bg = nullptr;
+        // the candidate roles borrow the tile workgroup's LDS: a parameter vector too long for it keeps the lockstep scheme
+        const size_t role_lds = (Np + 2 * Nv + 1) * sizeof(double) + unpack_lds_bytes() + 32;
+        I.fused_ok = role_lds <= sizeof(tile::TileLds<tile::M_FAST_DIRECT, 64>);
     }
     DCHK(hipStreamSynchronize(st));
     return TAMCMC_OK;
@@ -882,7 +924,7 @@ int DevSampler::download_proposal(int m, double *cov, double *mu, double *sigma)
 }
 
 // n_iter iterations starting at iteration counter `it0`; learn[i] != 0 -> adaptation after iteration it0+i.
-// Stretches without adaptation run as speculative rounds (k_spec); the others one iteration per round (k_iterate).
+// Stretches without adaptation run as fused steps (A), the others in lockstep (B); see the head of this file.
 int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, double *stats) {
     Impl &I = *impl;
     tamcmc_hip_ctx *c = I.ctx;
@@ -891,17 +933,19 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     DCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t C = (size_t)a.C, Nv = (size_t)a.Nv;
-    const int D = a.D;
     const int tb = tile_bins(c->wgs, c->K);
     a.ntiles = (a.desc.Nx + tb - 1) / tb;
-    DCHK(c->d_part.reserve(C * (size_t)D * (size_t)a.ntiles * 2));
+    DCHK(c->d_part.reserve(C * (size_t)a.ntiles * 2));
     a.partials = c->d_part.p;
     a.tile_bins = tb;
     a.bg = nullptr;
-    if (c->precision == TAMCMC_PRECISION_FAST) {
-        DCHK(c->d_bg.reserve(C * (size_t)D * (size_t)a.ntiles * 8));
+    const bool use_fused = I.fused_ok && c->step_scheme == 0 && c->wgs == 64 && (c->K == 4 || c->K == 8 || c->K == 16);
+    const size_t NS = (size_t)I.f.NS;
+    if (c->precision == TAMCMC_PRECISION_FAST) {  // background series per (slot, tile): C slots of (B), then 2 x NS slots of (A)
+        DCHK(c->d_bg.reserve((C + (use_fused ? 2 * NS : 0)) * (size_t)a.ntiles * 8));
         a.bg = c->d_bg.p;
     }
+    I.f.bg = (a.bg && use_fused) ? a.bg + C * (size_t)a.ntiles * 8 : nullptr;
     if (samples && I.smp_cap < (size_t)n_iter * C * Nv) {
         DCHK(I.dalloc(&a.samples, (size_t)n_iter * C * Nv));  // (older, smaller buffers are released with the sampler)
         I.smp_cap = (size_t)n_iter * C * Nv;
@@ -913,23 +957,33 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     DevSamplerArgs args = a;
     if (!samples) args.samples = nullptr;
     if (!stats) args.stats = nullptr;
-    // chain groups [goff[g], goff[g+1])
+    // chain groups [goff[g], goff[g+1]) of the lockstep scheme
     const int G = I.G;
     int goff[5];
     for (int g = 0; g <= G; g++) goff[g] = (int)(((long)a.C * g) / G);
     auto group_of = [&](int chain) { int g = 0; while (g + 1 < G && chain >= goff[g + 1]) g++; return g; };
-    LoglikeArgs la[4], las;
-    auto fill_la = [&](LoglikeArgs &l, int first_slot, int nslots, bool stamps) {
-        l.x = c->dx.p; l.y = c->dy.p; l.logx = c->dlogx.p; l.Nx = a.desc.Nx; l.B = nslots; l.ntiles = a.ntiles;
-        l.x0 = a.desc.x_first; l.step = a.desc.step;
-        l.mults = a.mults; l.offsets = a.pairs + 2 * first_slot; l.noise = a.noise + (size_t)first_slot * a.desc.stride; l.noise_stride = a.desc.stride;
-        l.nharvey = a.nh + first_slot; l.nnoise = a.nn + first_slot; l.partials = a.partials + (size_t)first_slot * a.ntiles * 2; l.model = nullptr;
-        l.dbg = (a.dbg && stamps) ? a.dbg + 8 : nullptr;
-        l.tile_rot = I.tile_rot;
-        l.bg_poly = a.bg ? a.bg + (size_t)first_slot * a.ntiles * 8 : nullptr;
+    LoglikeArgs la[4], lf[2];
+    auto fill_common = [&](LoglikeArgs &l, int B) {
+        l.x = c->dx.p; l.y = c->dy.p; l.logx = c->dlogx.p; l.Nx = a.desc.Nx; l.B = B; l.ntiles = a.ntiles;
+        l.x0 = a.desc.x_first; l.step = a.desc.step; l.noise_stride = a.desc.stride; l.model = nullptr; l.tile_rot = I.tile_rot;
     };
-    for (int g = 0; g < G; g++) fill_la(la[g], goff[g], goff[g + 1] - goff[g], g == 0);
-    fill_la(las, 0, a.C * D, true);
+    for (int g = 0; g < G; g++) {
+        LoglikeArgs &l = la[g];
+        const int first = goff[g];
+        fill_common(l, goff[g + 1] - goff[g]);
+        l.mults = a.mults; l.offsets = a.pairs + 2 * first; l.noise = a.noise + (size_t)first * a.desc.stride;
+        l.nharvey = a.nh + first; l.nnoise = a.nn + first; l.partials = a.partials + (size_t)first * a.ntiles * 2;
+        l.bg_poly = a.bg ? a.bg + (size_t)first * a.ntiles * 8 : nullptr;
+    }
+    for (int q = 0; q < 2; q++) {  // (A): evaluation m = chain m, its table in slot f.slot[q][m] of parity q's candidate block
+        LoglikeArgs &l = lf[q];
+        const FusedArgs &f = I.f;
+        fill_common(l, a.C);
+        l.mults = f.mults + (size_t)q * NS * a.desc.per; l.offsets = f.pairs + (size_t)q * 2 * NS; l.noise = f.noise + (size_t)q * NS * a.desc.stride;
+        l.nharvey = f.nh + (size_t)q * NS; l.nnoise = f.nn + (size_t)q * NS; l.partials = a.partials;
+        l.bg_poly = f.bg ? f.bg + (size_t)q * NS * a.ntiles * 8 : nullptr;
+        l.slot_map = f.slot + (size_t)q * C;
+    }
 
     int used_ev = 0;
     int P = I.parity;
@@ -951,11 +1005,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         return TAMCMC_OK;
     };
 
-    // ---- one iteration per round over [ia, ib): k_iterate settles iteration it-1 and proposes iteration it
+    // ---- (B) one iteration per round over [ia, ib): k_iterate settles iteration it-1 and proposes iteration it
     auto lockstep = [&](long ia, long ib) -> int {
         // the extra streams start after everything already enqueued on the context stream
-        DCHK(hipEventRecord(I.ev_fork, st));
-        for (int g = 1; g < G; g++) DCHK(hipStreamWaitEvent(I.gst[g], I.ev_fork, 0));
+        if (G > 1) {
+            DCHK(hipEventRecord(I.ev_fork, st));
+            for (int g = 1; g < G; g++) DCHK(hipStreamWaitEvent(I.gst[g], I.ev_fork, 0));
+        }
         const long len = ib - ia;
         const long ev_every = len > 32 ? len / 32 : 1;
         int pending = 0, have_pre = 0;
@@ -1018,75 +1074,58 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             DCHK(hipEventRecord(I.ev_join[g], I.gst[g]));
             DCHK(hipStreamWaitEvent(st, I.ev_join[g], 0));
         }
-        DCHK(hipStreamSynchronize(st));
-        // (with chain groups every launch carries C/G evaluations and overlaps the other groups' kernels)
-        return drain_events((double)len * G, len * (long)a.C);
-    };
-
-    // ---- speculative rounds over [ia, ib) (no adaptation inside): every chain ends having completed iteration ib-1
-    auto speculative = [&](long ia, long ib) -> int {
-        const long it_a = it0 + ia, it_b = it0 + ib;
-        std::vector<long> h_done(C);
-        std::vector<int> h_np(C), h_ph(C);
-        long cand0 = 0, cand1 = 0;
-        DCHK(hipMemcpyAsync(&cand0, a.counters + 4, sizeof(long), hipMemcpyDeviceToHost, st));
-        int first = 1;
-        long remaining = ib - ia, rounds_total = 0;
-        // expected iterations per round at the target acceptance rate: 1 + q + q^2 + ... (q = rejection probability)
-        double rate = 0, q = 1.0;
-        for (int k = 0; k < D; k++) { rate += q; q *= (1.0 - a.target_acceptance); }
-        for (int batch = 0; batch < 1000000; batch++) {
-            long rounds = (long)((double)remaining / rate) + 2;
-            const long ev_every = rounds > 16 ? rounds / 16 : 1;
-            for (long r = 0; r < rounds; r++) {
-                hipLaunchKernelGGL(k_spec, dim3(a.C * D), dim3(TB), I.lds_base, st, args, P, first, it_a, it_b, it0);
-                first = 0;
-                P ^= 1;
-                const bool timed = c->timing && (r % ev_every == 0) && used_ev < I.n_ev;
-                if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
-                DCHK(launch_loglike(las, c->precision, c->wgs, c->K, false, st));
-                if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
-            }
-            rounds_total += rounds;
-            DCHK(hipMemcpyAsync(h_done.data(), a.sp_done + (size_t)P * C, C * sizeof(long), hipMemcpyDeviceToHost, st));
-            DCHK(hipMemcpyAsync(h_np.data(), a.sp_nprop + (size_t)P * C, C * sizeof(int), hipMemcpyDeviceToHost, st));
-            DCHK(hipMemcpyAsync(h_ph.data(), a.sp_phase + (size_t)P * C, C * sizeof(int), hipMemcpyDeviceToHost, st));
-            DCHK(hipMemcpyAsync(&cand1, a.counters + 4, sizeof(long), hipMemcpyDeviceToHost, st));
+        if (c->timing) {  // (with chain groups every launch carries C/G evaluations and overlaps the other groups' kernels)
             DCHK(hipStreamSynchronize(st));
-            DCHK(hipGetLastError());
-            int rc = drain_events((double)rounds, 0);
-            if (rc) return rc;
-            long min_done = it_b;
-            bool settled = true;
-            for (size_t m = 0; m < C; m++) {
-                if (h_done[m] < min_done) min_done = h_done[m];
-                if (h_np[m] != 0 || h_ph[m] != 0) settled = false;
-            }
-            if (min_done >= it_b && settled) break;
-            remaining = it_b - min_done;
-            if (remaining < 1) remaining = 1;
+            return drain_events((double)len * G, len * (long)a.C);
         }
-        n_eval += cand1 - cand0;
-        (void)rounds_total;
         return TAMCMC_OK;
     };
 
-    // ---- split [0, n_iter) into stretches: quiet ones (no adaptation, at least MIN_SPEC long) run speculatively
-    const long MIN_SPEC = 8;  // shorter quiet stretches are not worth the drain rounds
+    // ---- (A) fused steps over [ia, ib) (no adaptation inside): one launch per iteration on the context stream
+    auto fused = [&](long ia, long ib) -> int {
+        const FusedArgs &f = I.f;
+        const int nbr = 4 * f.NS;                                     // candidate roles, a multiple of 8 (keeps the tiles' XCD mapping)
+        const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
+        const int grid_tiles = ntiles_pad * a.C;
+        const long len = ib - ia;
+        const long ev_every = len > 32 ? len / 32 : 1;
+        int q = P;
+        // entry: the candidates of iteration ia, built on the settled chains (state of parity q)
+        DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[q], it0 + ia, q, -1, ST_ENTRY, nbr));
+        for (long i = ia; i < ib; i++) {
+            const bool last = (i + 1 == ib);
+            const long rec = (samples || stats) ? i : (long)-1;
+            const bool timed = c->timing && ((i - ia) % ev_every == 0) && used_ev < I.n_ev;
+            if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
+            DCHK(launch_step(c->precision, c->K, (last ? 0 : nbr) + grid_tiles, st, args, f, lf[q], it0 + i, q, rec, ST_L | (last ? 0 : ST_BR),
+                             last ? 0 : nbr));
+            if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
+            q ^= 1;
+        }
+        P = q;
+        if (c->timing) {
+            DCHK(hipStreamSynchronize(st));
+            return drain_events((double)len, len * (long)a.C);
+        }
+        return TAMCMC_OK;
+    };
+
+    // ---- split [0, n_iter) into stretches: quiet ones (no adaptation, at least MIN_FUSED long) run fused
+    const long MIN_FUSED = 3;  // a stretch pays one entry launch
     auto quiet_end = [&](long from) { long q2 = from; while (q2 < n_iter && !(learn && learn[q2])) q2++; return q2; };
     long i = 0;
     while (i < n_iter) {
         const long jn = quiet_end(i);
-        if (D > 1 && jn - i >= MIN_SPEC) {
-            int rc = speculative(i, jn);
+        if (use_fused && jn - i >= MIN_FUSED) {
+            int rc = fused(i, jn);
             if (rc) return rc;
             i = jn;
             continue;
         }
-        long k = i;  // one iteration per round up to the start of the next long quiet stretch
+        long k = i;  // lockstep up to the start of the next long quiet stretch
         for (;;) {
             const long q2 = quiet_end(k);
-            if (D > 1 && q2 - k >= MIN_SPEC && k > i) break;
+            if (use_fused && q2 - k >= MIN_FUSED && k > i) break;
             k = q2;
             while (k < n_iter && learn && learn[k]) k++;
             if (k >= n_iter) break;
@@ -1095,35 +1134,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         if (rc) return rc;
         i = k;
     }
-    {  // iteration counter as the one-iteration engine leaves it
-        const long itn = it0 + n_iter;
-        DCHK(hipMemcpyAsync(a.counters, &itn, sizeof(long), hipMemcpyHostToDevice, st));
-    }
     I.parity = P;
-    if (a.dbg) {  // phase stamps of the last proposal workgroup of chain 0 / the middle tile (100 MHz wall clock)
-        long h[16];
-        DCHK(hipMemcpyAsync(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost, st));
-        DCHK(hipStreamSynchronize(st));
-        fprintf(stderr, "[k_iterate stamps us] settle %.2f | rng+matvec %.2f | scatter+prior %.2f (constraints %.2f) | unpack %.2f (visibilities %.2f, rows %.2f)\n",
-                (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[4] - h[2]) * 0.01, (h[3] - h[2]) * 0.01, (h[6] - h[4]) * 0.01, (h[5] - h[4]) * 0.01,
-                (h[7] - h[5]) * 0.01);
-        const long *k = h + 8;
-        if (k[7] == 77 && a.ntiles <= 4096) {  // timeline of the last k_loglike launch of chain group 0
-            const int nb = (G > 1 ? goff[1] : a.C), nw = nb * a.ntiles;
-            std::vector<long> w(2 * (size_t)nw);
-            DCHK(hipMemcpy(w.data(), a.dbg + 16, w.size() * sizeof(long), hipMemcpyDeviceToHost));
-            long t0 = w[0], t1 = w[1];
-            for (int q = 0; q < nw; q++) { if (w[2 * q] && w[2 * q] < t0) t0 = w[2 * q]; if (w[2 * q + 1] > t1) t1 = w[2 * q + 1]; }
-            std::vector<double> dur, start;
-            for (int q = 0; q < nw; q++) if (w[2 * q]) { dur.push_back((w[2 * q + 1] - w[2 * q]) * 0.01); start.push_back((w[2 * q] - t0) * 0.01); }
-            std::sort(dur.begin(), dur.end()); std::sort(start.begin(), start.end());
-            auto pct = [](const std::vector<double> &v, double p) { return v.empty() ? 0.0 : v[(size_t)(p * (v.size() - 1))]; };
-            fprintf(stderr, "[k_loglike timeline us] %zu workgroups, first start -> last end %.2f | start p50 %.2f p90 %.2f max %.2f | duration p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
-                    dur.size(), (t1 - t0) * 0.01, pct(start, .5), pct(start, .9), pct(start, 1.), pct(dur, .1), pct(dur, .5), pct(dur, .9), pct(dur, 1.));
-        }
-        fprintf(stderr, "[k_loglike stamps us, middle tile] prologue %.2f | staging %.2f | near %.2f | far+reduce %.2f | horner %.2f | epilogue %.2f\n",
-                (k[1] - k[0]) * 0.01, (k[2] - k[1]) * 0.01, (k[3] - k[2]) * 0.01, (k[4] - k[3]) * 0.01, (k[5] - k[4]) * 0.01, (k[6] - k[5]) * 0.01);
-    }
     DCHK(hipGetLastError());
     if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));

@@ -133,14 +133,15 @@ struct WaveSync {
     }
 };
 
-// Background series of every tile of evaluation slot `slot` (bg_series.h), tiles strided over lanes first .. first+nw-1.
+// Background series of the tiles [t_lo, t_hi) of evaluation slot `slot` (bg_series.h), strided over lanes first .. first+nw-1.
 __device__ inline void wg_bg_tiles(const ModelDesc &d, const double *s_params, const mt::Shared *S, int slot, const TablePtrs &T, int first,
-                                   int nw) {
+                                   int nw, int t_lo = 0, int t_hi = 1 << 30) {
     const int tid = threadIdx.x;
     const double *np_ = s_params + S->L.o_noise;
     const int nh = S->nharvey, nn = S->L.Nnoise;
+    if (t_hi > T.ntiles) t_hi = T.ntiles;
     if (tid >= first && tid < first + nw)
-        for (int t = tid - first; t < T.ntiles; t += nw) {
+        for (int t = t_lo + tid - first; t < t_hi; t += nw) {
             double xc, h;
             bg::tile_geometry(t, T.tile_bins, d.x_first, d.step, xc, h);
             if (!bg::series_valid(xc, h)) continue;
@@ -158,7 +159,7 @@ __device__ inline void wg_bg_tiles(const ModelDesc &d, const double *s_params, c
 // m-visibilities): pass vis_done = true to wg_unpack afterwards.
 // early_rows (with vis_in_prior, 256 threads): a third group of lanes writes the table rows of slot `early_slot` while the
 // visibilities are still being computed, with hv = H; wg_unpack(rows_done = true) multiplies the visibilities in.
-__device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, bool prepare_unpack, long *dbg = nullptr,
+__device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, bool prepare_unpack,
                                       bool vis_in_prior = false, const TablePtrs *early_rows = nullptr, int early_slot = 0) {
     const int Np = d.Np;
     const bool split = vis_in_prior && prepare_unpack && blockDim.x >= 128 && (blockDim.x & 63) == 0;
@@ -186,7 +187,6 @@ __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params
         if (st != TAMCMC_OK) *u.status = st;
     }
     __syncthreads();
-    if (dbg && threadIdx.x == 0) dbg[3] = (long)wall_clock64();
     const int n_extra = (d.prior_class == 2) ? pr::ms_global_extra_terms(d.plength, d.extra) : 0;
     double f = 0;
     int st = TAMCMC_OK;
@@ -210,15 +210,59 @@ __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params
     return *u.reject ? -INFINITY : f;
 }
 
+// The same log-prior by ONE wave (blockDim.x == 64), bit for bit the value wg_log_prior returns in the proposal kernel's 256-thread
+// layout: there `virt` (= 128) lanes take the additive terms (term t on lane t mod virt, in increasing t), each wave of 64 lanes sums
+// its lanes with a shuffle tree and the waves are added in order.  Here every lane plays virt/64 virtual lanes, one after the other.
+__device__ inline double wave_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, int virt) {
+    const int Np = d.Np, tid = threadIdx.x;
+    {
+        int st = TAMCMC_OK;
+        mt::xreal c = 0;
+        if (d.prior_class == 2) {
+            c = pr::ms_global_constraints(s_params, d.plength, d.priors_switch, d.extra, &st, tid, 64);
+            if (tid == 1) {
+                double fit[2];
+                mt::linfit_index(s_params + d.plength[0] + d.plength[1], d.plength[2], fit);
+                *u.dnu = fit[0];
+            }
+        } else if (d.prior_class == 3) {
+            if (tid == 0) c = pr::local_constraints(s_params, d.plength, d.priors_switch, d.extra);
+        } else {
+            c = pr::neg_inf();
+            st = TAMCMC_ERR_BAD_MODEL;
+        }
+        if (c != 0) *u.reject = 1;
+        if (st != TAMCMC_OK) *u.status = st;
+    }
+    __syncthreads();
+    const int n_extra = (d.prior_class == 2) ? pr::ms_global_extra_terms(d.plength, d.extra) : 0;
+    int st = TAMCMC_OK;
+    double total = 0;
+    for (int h = 0; h * 64 < virt; h++) {
+        double f = 0;
+        for (int t = h * 64 + tid; t < Np + n_extra; t += virt) {
+            if (t < Np) f = f + pr::generic_prior_term(s_params, Np, d.priors, d.priors_switch, t, &st);
+            else f = f + pr::ms_global_extra_term(s_params, d.plength, d.extra, *u.dnu, t - Np);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) f = f + __shfl_down(f, off, 64);
+        f = __shfl(f, 0, 64);
+        total = (h == 0) ? f : total + f;
+    }
+    if (st != TAMCMC_OK) *u.status = st;
+    __syncthreads();
+    return *u.reject ? -INFINITY : total;
+}
+
 // params (LDS) -> table rows of evaluation slot `slot` (+ noise row, range, counts).  `live` = the prior is finite
 // (model_def.cpp:472,476-480 skips the model otherwise).  u.S must hold shared_scalars_base (wg_log_prior did it).
+// empty_on_fail: a failed table leaves an EMPTY slot (nn = 0: the likelihood kernel skips it) instead of a placeholder noise row.
 __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, const UnpackLds &u, int slot, const TablePtrs &T,
-                                 bool live, long *dbg = nullptr, bool vis_done = false, bool rows_done = false) {
+                                 bool live, bool vis_done = false, bool rows_done = false, bool empty_on_fail = false) {
     const int tid = threadIdx.x, nt = blockDim.x, per = d.per;
     mt::Shared *S = u.S;
     if (live) {
         if (!vis_done) visibilities_stage(u, tid, WgSync());  // workgroup-uniform
-        if (dbg && threadIdx.x == 0) dbg[5] = (long)wall_clock64();
         if (rows_done) {  // rows already written with hv = H (wg_log_prior, early_rows): the visibilities are known now
             for (int e = tid; e < per * 7; e += nt) {
                 tamcmc_multiplet *r = &T.mults[(size_t)slot * per + e / 7];
@@ -231,7 +275,6 @@ __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, con
                                                    &T.mults[(size_t)slot * per + idx]);
                 if (st) *u.status = st;
             }
-        if (dbg && threadIdx.x == 0) dbg[7] = (long)wall_clock64();
         for (int i = tid; i < S->L.Nnoise; i += nt) T.noise[(size_t)slot * d.stride + i] = fabs(s_params[S->L.o_noise + i]);
         if (T.bg && !rows_done)  // (with early rows wg_log_prior's term lanes already did it)
             wg_bg_tiles(d, s_params, S, slot, T, (nt > 64) ? 64 : 0, (nt > 64) ? nt - 64 : nt);  // beside the first wave's multiplet rows
@@ -242,7 +285,7 @@ __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, con
         T.pairs[2 * slot] = slot * per;
         T.pairs[2 * slot + 1] = ok ? (slot + 1) * per : slot * per;
         T.nh[slot] = ok ? S->nharvey : 0;
-        T.nn[slot] = ok ? S->L.Nnoise : 1;
+        T.nn[slot] = ok ? S->L.Nnoise : (empty_on_fail ? 0 : 1);
         if (!ok) T.noise[(size_t)slot * d.stride] = 1.0;  // placeholder row; the caller rejects / NaNs the evaluation
     }
     if (T.bg && !(live && (*u.status == TAMCMC_OK)))  // ... with the matching background series (constant 1)

@@ -9,6 +9,7 @@
 #include "../../include/tamcmc_sampler.h"
 #include "dev_sampler.h"
 #include "host_sampler.h"
+#include "rng.h"
 
 using namespace tamcmc;
 
@@ -100,6 +101,7 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
     g.MALA.use_drift = c->use_drift;
     g.MALA.seed = c->seed;
     g.MALA.fd_step_rel = c->fd_step_rel > 0 ? c->fd_step_rel : 1e-7;
+    g.MALA.swap_rule = c->swap_rule == 1 ? 1 : 0;
     s->mala = std::make_unique<MALA>(&g);
     s->ctx = ctx;
     s->cur = std::make_unique<Model_def>(&g, s->mala->Tcoefs, false, ctx);
@@ -115,6 +117,7 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
         di.plength = in.plength.data(); di.index_to_relax = idx.data(); di.priors_switch = in.priors_names_switch.data();
         di.priors = in.priors.a.data(); di.extra_priors = in.extra_priors.data(); di.Tcoefs = s->mala->Tcoefs.data();
         di.seed = c->seed; di.dN_mixing = (long)c->dN_mixing; di.chain_groups = c->chain_groups;
+        di.swap_rule = g.MALA.swap_rule;
         di.c0 = c->c0; di.epsilon1 = c->epsilon1; di.epsi2 = c->epsilon2; di.A1 = c->A1; di.target_acceptance = c->target_acceptance;
         int rc = s->dev->init(ctx, di);
         if (rc) return rc;
@@ -194,6 +197,33 @@ int tamcmc_sampler_run_packed(tamcmc_sampler *const *s, int32_t S, int64_t n_ite
     for (auto &t : th) t.join();
     for (int32_t k = 0; k < S; k++)
         if (rc[(size_t)k]) return rc[(size_t)k];
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_draws(const tamcmc_sampler *s, int64_t iteration, double *z, double *u_accept, double *u_swap, int32_t *ind_A) {
+    if (!s || iteration < 0) return TAMCMC_ERR_BAD_ARG;
+    const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    const uint64_t seed = s->mala->get_seed();
+    for (long m = 0; m < Nc; m++) {
+        if (z)
+            for (long k = 0; k < Nv; k += 2) {  // same addressing as MALA::new_prop_values / dev_sampler.hip::normals_into
+                double z0, z1;
+                rng_normal2(seed, RNG_PROPOSAL, (uint32_t)m, (uint64_t)iteration, (uint32_t)(k / 2), z0, z1);
+                z[(size_t)(m * Nv + k)] = z0;
+                if (k + 1 < Nv) z[(size_t)(m * Nv + k + 1)] = z1;
+            }
+        if (u_accept) {
+            double u, unused;
+            rng_uniform2(seed, RNG_ACCEPT, (uint32_t)m, (uint64_t)iteration, 0, u, unused);
+            u_accept[m] = u;
+        }
+    }
+    double u, u2;
+    rng_uniform2(seed, RNG_SWAP, 0, (uint64_t)iteration, 0, u, u2);
+    int a = (int)(u2 * (double)(Nc - 1));
+    if (a > Nc - 2) a = (int)Nc - 2;
+    if (u_swap) *u_swap = u;
+    if (ind_A) *ind_A = Nc > 1 ? a : -1;
     return TAMCMC_OK;
 }
 

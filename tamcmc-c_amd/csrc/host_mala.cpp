@@ -58,6 +58,7 @@ MALA::MALA(Config *cfg) {
     lambda_temp = cfg->MALA.lambda_temp;
     use_drift = cfg->MALA.use_drift != 0;
     fd_step_rel = cfg->MALA.fd_step_rel;
+    swap_rule = cfg->MALA.swap_rule;
     Nt_learn = cfg->MALA.Nt_learn;
     periods_learn = cfg->MALA.periods_learn;
     dN_mixing = cfg->MALA.dN_mixing;
@@ -231,7 +232,9 @@ int MALA::parallel_tempering(Model_def *model) {
         model->logPosterior[(size_t)ind_A] = (double)(logL_B_TA + prB);
         model->logLikelihood[(size_t)ind_B] = (double)logL_A_TB;
         model->logPrior[(size_t)ind_B] = prA;
-        model->logPosterior[(size_t)ind_B] = (double)(logL_A_TB + prA);
+        // MALA.cpp:444 reads logPrior[ind_A] after :433 has overwritten it with B's: swap_rule 1 reproduces that (B keeps its own old prior
+        // in the stored posterior); the default stores the posterior of the position B receives
+        model->logPosterior[(size_t)ind_B] = (double)(logL_A_TB + (swap_rule == 1 ? prB : prA));
         std::swap(model->moved[(size_t)ind_A], model->moved[(size_t)ind_B]);
         std::swap(model->Pmove[(size_t)ind_A], model->Pmove[(size_t)ind_B]);
         if (use_drift) {  // the stored gradient follows the position: grad = (likelihood share) T_old/T_new + (prior share)

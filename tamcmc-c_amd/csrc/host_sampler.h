@@ -60,6 +60,7 @@ struct Config {
         // additions of this build (no reference counterpart)
         uint64_t seed = 20240229;             // reference: time(NULL), MALA.cpp:62
         double fd_step_rel = 1e-7;            // forward-difference step h_k = fd_step_rel * max(|theta_k|, 1e-3)
+        int swap_rule = 0;                    // 1: chain B's logPosterior after a swap as MALA.cpp:433,444 execute it (see tamcmc_sampler.h)
     } MALA;
     struct {
         int model_fct_name_switch = 0, likelihood_fct_name_switch = 0, prior_fct_name_switch = 2;
@@ -141,6 +142,7 @@ class MALA {  // MALA.h:26-69
     double epsi2;
     bool use_drift;
     double fd_step_rel;
+    int swap_rule = 0;
     std::vector<Matrix> Lchol;          // cached factor of (covarmat+epsilon2)*sigma per chain
     std::vector<char> Lchol_valid;
     // Langevin state (use_drift): gradient of the tempered log-posterior at the current / proposed position

@@ -17,8 +17,12 @@ struct LoglikeArgs {
     double x0, step;      // regular grid: x[i] = x0 + i*step (far-field tile geometry)
     int B;                // evaluations in this launch
     int ntiles;           // filled by launch_loglike
-    int probe = 0;        // tools/phase_probe.py only (TAMCMC_PROBE_SKIP): bit mask of kernel phases to skip -- results are then wrong
+#ifdef TAMCMC_PROBE        // the probe build only (make probe -> libtamcmc_hip_probe.so, used by tools/): never in the product library
+    int probe = 0;        // bit mask of kernel phases to skip -- results are then wrong (tools/phase_probe.py)
+    long *dbg = nullptr;  // phase stamps of one workgroup / per-workgroup timeline
+#endif
     int tile_rot = 0;     // tile dispatched first (launch order wraps around); any value in [0, ntiles) gives the same results
+    const int32_t *slot_map = nullptr;  // nullptr: evaluation b reads table slot b; else slot_map[b] & 0xffff (fused sampler step)
     const tamcmc_multiplet *mults;  // concatenated multiplet tables
     const int32_t *offsets;         // [2B] (begin,end) multiplet range per evaluation
     const double *noise;            // [B x noise_stride] |noise params|
@@ -27,7 +31,6 @@ struct LoglikeArgs {
     const int32_t *nnoise;          // [B]
     double *partials;               // [B x ntiles x 2]
     double *model;                  // [B x Nx] or nullptr
-    long *dbg = nullptr;            // optional phase stamps of one workgroup (TAMCMC_DEBUG_STAMPS)
     // FAST far field: [B x ntiles x 8] background series per (evaluation, tile) built with the table (bg_series.h);
     // nullptr -> every tile's workgroup computes its own (same arithmetic, same result)
     const double *bg_poly = nullptr;

@@ -41,7 +41,7 @@ constexpr int WG = 256;
 
 struct Prep {  // one parameter vector's solver inputs
     int Lp, Lg, ng_min, status;
-    int probe_dense, pad_;         // TAMCMC_ARMM_DENSE=1: walk the whole grid (the reference's way) instead of the pole-structured scan
+    int probe_dense, pad_;         // TAMCMC_OPT_ARMM_DENSE_SCAN: walk the whole grid (the reference's way) instead of the pole-structured scan
     int ig0[MAXP];                 // first g mode inside the zone of p mode ip, -1: none (the reference skips the pair)
     double nu_p[MAXP], dnu_loc[MAXP], dnup[MAXP];
     double Dnu_p, DPl, alpha, q, zone, resol, fact, keep_lo, keep_hi;
@@ -80,7 +80,7 @@ __device__ __forceinline__ bool changes_sign(double a, double b) {  // sign_chan
 //          evaluations instead of hundreds) -- and the three cells around each pole, which are evaluated directly (the pole's own
 //          cell changes sign when the drop crosses zero; one cell of margin on each side absorbs the rounding of the pole position).
 //          One LANE per unit: unit 0 = the stretch before the first pole, unit j+1 = pole j and the stretch after it.  Windows that
-//          start at nu = 0 or hold an unreasonable number of poles take the dense walk (TAMCMC_ARMM_DENSE=1 forces it).
+//          start at nu = 0 or hold an unreasonable number of poles take the dense walk (TAMCMC_OPT_ARMM_DENSE_SCAN forces it).
 //  refine: one LANE per candidate: the local grid of step resol*fact over [x0 - 2 resol, x0 + 2 resol], lin_interpol with x = p-g,
 //          y = nu at 0 (interpol.cpp:13-43), the 0.1 % ratio test.  Without a pole inside the window p-g is increasing there and the
 //          bracketing pair is found by bisection; the rare windows that hold both a bracket and a pole are walked point by point by
@@ -637,8 +637,7 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
                      int *per_out, int *stride_out, int *first_err, int *tile_rot_out) {
     using namespace rgb;
     const bool cte_width = (model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4_ID);
-    const char *env_dense = getenv("TAMCMC_ARMM_DENSE");
-    const bool dense_scan = env_dense && atoi(env_dense) != 0;
+    const bool dense_scan = c->armm_dense != 0;  // TAMCMC_OPT_ARMM_DENSE_SCAN
     const double *hx = c->hx.data();
     const int64_t Nx = c->Nx;
     const double step = hx[2] - hx[1];  // models.cpp:4719

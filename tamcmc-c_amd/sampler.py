@@ -17,7 +17,7 @@ class SamplerConfig(C.Structure):
                 ("epsilon1", C.c_double), ("epsilon2", C.c_double), ("A1", C.c_double), ("delta", C.c_double),
                 ("delta_x", C.c_double), ("Nt_learn", _i64p), ("periods_learn", _i64p), ("n_Nt_learn", C.c_int32),
                 ("engine", C.c_int32), ("dN_mixing", C.c_int64), ("init_errors", _dp), ("seed", C.c_uint64),
-                ("fd_step_rel", C.c_double), ("chain_groups", C.c_int32)]
+                ("fd_step_rel", C.c_double), ("chain_groups", C.c_int32), ("swap_rule", C.c_int32)]
 
 
 EXTRA_ABI += [
@@ -26,6 +26,7 @@ EXTRA_ABI += [
     ("tamcmc_sampler_nvars", C.c_int64, [_vp]),
     ("tamcmc_sampler_run", C.c_int, [_vp, C.c_int64, _dp, _dp]),
     ("tamcmc_sampler_run_packed", C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int64, C.POINTER(_dp), C.POINTER(_dp)]),
+    ("tamcmc_sampler_draws", C.c_int, [_vp, C.c_int64, _dp, _dp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("tamcmc_sampler_get_state", C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _i64p]),
     ("tamcmc_sampler_get_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp]),
     ("tamcmc_sampler_set_proposal", C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_double]),
@@ -62,7 +63,7 @@ class Sampler:
     def __init__(self, ctx: HipContext, star, nchains=5, lambda_temp=3.5, use_drift=0, seed=20240229, p=1.0,
                  target_acceptance=0.234, c0=10.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, delta=0.0, delta_x=1e-10,
                  Nt_learn=(1000, 1500, 100000), periods_learn=(1, 1), dN_mixing=1, init_errors=None, fd_step_rel=1e-7,
-                 engine="host", chain_groups=0):
+                 engine="host", chain_groups=0, swap_rule=0):
         self._L = _rebind()
         self.ctx = ctx
         self.nchains = int(nchains)
@@ -92,6 +93,7 @@ class Sampler:
         cfg.dN_mixing, cfg.init_errors, cfg.seed, cfg.fd_step_rel = int(dN_mixing), _p(keep["err"]), int(seed), fd_step_rel
         cfg.engine = {"host": 0, "device": 1}[engine]
         cfg.chain_groups = int(chain_groups)
+        cfg.swap_rule = int(swap_rule)
         h = _vp()
         st = self._L.tamcmc_sampler_create(C.byref(h), ctx._h, C.byref(cfg))
         if st != OK:
@@ -129,6 +131,22 @@ class Sampler:
                                          _p(out["Pmove"]), _p(out["sigma"]), _p(cnt, _i64p))
         out.update(iteration=int(cnt[0]), accepted0=int(cnt[1]), swap_attempts=int(cnt[2]), swaps=int(cnt[3]))
         return out
+
+    def draws(self, iteration):
+        """The random numbers iteration `iteration` consumes: (z [Nchains x Nvars], u_accept [Nchains], u_swap, ind_A)."""
+        z, u = np.zeros((self.nchains, self.nvars)), np.zeros(self.nchains)
+        us, ia = C.c_double(0), C.c_int32(0)
+        rc = self._L.tamcmc_sampler_draws(self._h, int(iteration), _p(z), _p(u), C.byref(us), C.byref(ia))
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_draws")
+        return z, u, us.value, ia.value
+
+    def proposal_law(self):
+        """(mu [Nchains x Nvars], covarmat [Nchains x Nvars x Nvars], sigma [Nchains]) of every chain."""
+        mu, cov = np.zeros((self.nchains, self.nvars)), np.zeros((self.nchains, self.nvars, self.nvars))
+        for m in range(self.nchains):
+            mu[m], cov[m] = self.get_proposal(m)
+        return mu, cov, self.state()["sigma"]
 
     def set_state(self, vars, iteration=-1):
         v = _f64(vars)

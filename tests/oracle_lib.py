@@ -115,6 +115,35 @@ def load(fast=False):
     lib.orc_rgb_v4_cte_modes.argtypes = [c_dp, c_ip, C.c_double, C.POINTER(RgbModes)]
     lib.orc_rgb_modes_free.restype = None
     lib.orc_rgb_modes_free.argtypes = [C.POINTER(RgbModes)]
+
+    # one sampler iteration with explicit draws (sampler_oracle.c)
+    class SamplerStar(C.Structure):
+        _fields_ = [("model_id", C.c_int), ("prior_class", C.c_int), ("Nparams", C.c_long), ("Nvars", C.c_long), ("Nx", C.c_long),
+                    ("Nchains", C.c_long), ("plength", c_ip), ("index_to_relax", c_ip), ("priors_switch", c_ip), ("priors", c_dp),
+                    ("extra_priors", c_dp), ("x", c_dp), ("y", c_dp), ("Tcoefs", c_dp), ("init_logL", c_dp),
+                    ("likelihood_params", C.c_double), ("epsilon1", C.c_double), ("epsi2", C.c_double), ("A1", C.c_double),
+                    ("target_acceptance", C.c_double), ("c0", C.c_double)]
+
+    lib.SamplerStar = SamplerStar
+    lib.orc_p1_fct.restype = ld
+    lib.orc_p1_fct.argtypes = [ld, ld, ld]
+    lib.orc_p2_fct.restype = None
+    lib.orc_p2_fct.argtypes = [c_dp, C.c_long, C.c_double]
+    lib.orc_p3_fct.restype = None
+    lib.orc_p3_fct.argtypes = [c_dp, C.c_long, C.c_double]
+    lib.orc_update_proposal.restype = None
+    lib.orc_update_proposal.argtypes = [c_dp, c_dp, c_dp, c_dp, C.c_long, ld, ld, ld, ld, ld]
+    lib.orc_new_prop_values.restype = C.c_int
+    lib.orc_new_prop_values.argtypes = [c_dp, C.c_double, C.c_double, c_dp, c_dp, C.c_long, c_dp, c_dp]
+    lib.orc_mh_accept.restype = C.c_int
+    lib.orc_mh_accept.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, c_dp]
+    lib.orc_parallel_tempering.restype = C.c_int
+    lib.orc_parallel_tempering.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, C.c_long, C.c_long, C.c_int, C.c_double, C.c_int, c_dp]
+    lib.orc_learn_at.restype = C.c_int
+    lib.orc_learn_at.argtypes = [C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_long]
+    lib.orc_sampler_iteration.restype = C.c_int
+    lib.orc_sampler_iteration.argtypes = [C.POINTER(SamplerStar), C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, c_dp, c_dp, c_dp,
+                                          c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp]
     return lib
 
 
@@ -178,6 +207,30 @@ class Oracle:
                    Hl1=take(m.Hl1, m.N1), a1_l1=take(m.a1_l1, m.N1), ksi=take(m.ksi, m.N1), g=np.array(list(m.g)))
         self.lib.orc_rgb_modes_free(C.byref(m))
         return rc, out
+
+    # ---- one sampler iteration with explicit draws (sampler_oracle.c) ----
+    def sampler_iteration(self, star, y, Tcoefs, init_logL, state, law, i, z, u_mh, learn=False, do_swap=False, ind_A=0, u_swap=1.0,
+                          literal_444=False, p=1.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, target_acceptance=0.234, c0=10.0):
+        """One pass of MALA::execute's loop body.  state = dict(params, vars, logL, logPrior, logPost) [copied], law = (mu, cov, sigma)
+        [copied].  Returns (new state incl. moved / Pmove / swapped / prop_vars / prop_stats, new law, rc)."""
+        f = lambda a: np.ascontiguousarray(np.array(a, dtype=np.float64, copy=True))
+        st = {k: f(state[k]) for k in ("params", "vars", "logL", "logPrior", "logPost")}
+        mu, cov, sigma = f(law[0]), f(law[1]), f(law[2])
+        C_, Nv = st["vars"].shape
+        keep = dict(pl=np.ascontiguousarray(star.plength, dtype=np.int32), idx=np.ascontiguousarray(star.index_to_relax, dtype=np.int32),
+                    sw=np.ascontiguousarray(star.priors_switch, dtype=np.int32), pr=f(star.priors), ex=f(np.resize(np.append(star.extra_priors, np.zeros(10)), 10)),
+                    x=f(star.x), y=f(y), T=f(Tcoefs), il=f(init_logL))
+        S = self.lib.SamplerStar(int(star.model_id), int(star.prior_class), st["params"].shape[1], Nv, keep["x"].size, C_, _ip(keep["pl"]),
+                                 _ip(keep["idx"]), _ip(keep["sw"]), _dp(keep["pr"]), _dp(keep["ex"]), _dp(keep["x"]), _dp(keep["y"]), _dp(keep["T"]),
+                                 _dp(keep["il"]), float(p), epsilon1, epsilon2, A1, target_acceptance, c0)
+        z, u = f(z), f(u_mh)
+        moved, Pmove, swapped = np.zeros(C_, dtype=np.int32), np.zeros(C_), np.zeros(1, dtype=np.int32)
+        pv, ps = np.zeros((C_, Nv)), np.zeros((C_, 3))
+        rc = self.lib.orc_sampler_iteration(C.byref(S), int(i), int(learn), int(do_swap), int(ind_A), float(u_swap), int(literal_444), _dp(z), _dp(u),
+                                            _dp(st["params"]), _dp(st["vars"]), _dp(st["logL"]), _dp(st["logPrior"]), _dp(st["logPost"]), _ip(moved),
+                                            _dp(Pmove), _dp(mu), _dp(cov), _dp(sigma), _ip(swapped), _dp(pv), _dp(ps))
+        st.update(moved=moved, Pmove=Pmove, swapped=int(swapped[0]), prop_vars=pv, prop_stats=ps)
+        return st, (mu, cov, sigma), rc
 
     def amplitude_ratio(self, l, inc_deg):
         v = np.zeros(2 * l + 1)

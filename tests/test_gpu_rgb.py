@@ -86,7 +86,7 @@ def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth, cte):
     ctx.close()
 
 
-def test_structured_scan_finds_the_cells_of_the_dense_walk(pkg, synth, monkeypatch):
+def test_structured_scan_finds_the_cells_of_the_dense_walk(pkg, synth):
     """The mixed-mode solver's first pass looks for grid cells where p(nu) - g(nu) changes sign.  The reference walks every grid
     point (solver_mm.cpp:330-376); the device scan uses the function's structure instead (poles of tan in closed form, bisection on
     the grid index between them: csrc/rgb_prestep.hip).  Both must deliver the same cells, hence bit-identical model rows -- over
@@ -109,7 +109,7 @@ def test_structured_scan_finds_the_cells_of_the_dense_walk(pkg, synth, monkeypat
         ctx.set_spectrum(x, np.ones_like(x))
         out = {}
         for dense in ("1", "0"):
-            monkeypatch.setenv("TAMCMC_ARMM_DENSE", dense)
+            ctx.set_option(pkg.OPT_ARMM_DENSE_SCAN, int(dense))
             logL, rows, st = ctx.loglike_params_batch(pkg.MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4, P, pl, None, want_model=True)
             assert (st == 0).all(), (c, st)
             out[dense] = (logL, rows)

@@ -55,29 +55,36 @@ def test_device_engine_follows_host_engine(pkg, oracle, synth, ctx):
     h.close(); d.close()
 
 
-@pytest.mark.parametrize("dN_mixing,learn", [(1, None), (3, None), (7, (40, 90)), (0, None)])
-def test_speculative_rounds_are_bitwise_the_sequential_chain(pkg, oracle, synth, ctx, monkeypatch, dN_mixing, learn):
-    """Stretches without adaptation run D candidates per chain and round (k_spec); every random number is addressed by
-    (chain, iteration), so the samples, statistics and swap counts must be IDENTICAL to one iteration per round."""
+@pytest.mark.parametrize("dN_mixing,learn", [(1, None), (3, None), (7, (40, 90)), (0, None), (1, (5, 30))])
+def test_fused_steps_are_bitwise_the_lockstep_chain(pkg, oracle, synth, ctx, dN_mixing, learn):
+    """Stretches without adaptation run one fused launch per iteration (k_step: likelihood tiles with the settle step in their tail +
+    the branch-ahead candidates of the next iteration); the lockstep kernels (k_iterate, k_loglike) do the same work in sequence.
+    Same random numbers, same arithmetic, same summation orders: samples, statistics, swap counts and the final state must be
+    IDENTICAL, whatever the mixing period and wherever the adaptation window falls."""
     star = _star_with_data(pkg, oracle, synth)
     ctx.set_spectrum(star.x, star.y)
     Nt = learn if learn else (10**9, 10**9 + 1)
     kw = dict(nchains=7, lambda_temp=1.4, seed=23, Nt_learn=Nt, periods_learn=(2,), dN_mixing=dN_mixing)
     out = []
-    for depth in ("1", "3", "4"):
-        monkeypatch.setenv("TAMCMC_SPEC_DEPTH", depth)
+    for scheme in (1, 0):
+        ctx.set_option(pkg.OPT_STEP_SCHEME, scheme)
         d = pkg.Sampler(ctx, star, engine="device", **kw)
         s1, t1 = d.run(150, stats=True)
         s2, t2 = d.run(61, stats=True)   # a second call continues the same chains
-        out.append((np.concatenate([s1, s2]), np.concatenate([t1, t2]), d.state()))
+        s3, t3 = d.run(2, stats=True)    # shorter than a fused stretch: lockstep either way
+        out.append((np.concatenate([s1, s2, s3]), np.concatenate([t1, t2, t3]), d.state()))
         d.close()
-    for smp, st, state in out[1:]:
-        assert np.array_equal(smp, out[0][0])
-        assert np.array_equal(st, out[0][1])
-        for k in ("iteration", "swaps", "swap_attempts"):
-            assert state[k] == out[0][2][k], k
-        assert np.array_equal(state["vars"], out[0][2]["vars"]) and np.array_equal(state["logL"], out[0][2]["logL"])
+    ctx.set_option(pkg.OPT_STEP_SCHEME, 0)
+    smp, st, state = out[1]
+    assert np.array_equal(smp, out[0][0])
+    assert np.array_equal(st, out[0][1])
+    for k in ("iteration", "swaps", "swap_attempts", "accepted0"):
+        assert state[k] == out[0][2][k], k
+    for k in ("vars", "logL", "logPrior", "logPost", "Pmove", "sigma"):
+        assert np.array_equal(state[k], out[0][2][k]), k
     assert (out[0][0][:, 0] != out[0][0][0, 0]).any()
+    if dN_mixing:
+        assert 0 < state["swaps"] <= state["swap_attempts"]
 
 
 def test_device_engine_learning_adapts(pkg, oracle, synth, ctx):

@@ -1,0 +1,117 @@
+"""Rows a10 / N4 against the ORACLE (-m gpu): one iteration of each engine (host-driven mirror of MALA::execute, device-resident
+k_iterate / fused step) equals oracle/sampler_oracle.c's restatement of MALA.cpp:645-703 fed with the SAME random numbers
+(tamcmc_sampler_draws), on the headline shape: C3 star, 1e5 bins x 111 parameters (93 free) x 20 tempered chains.
+Cases: with and without adaptation, swap pair inside a chain group and across the two groups, swap accepted and refused, both
+rules for chain B's stored posterior (MALA.cpp:444 as executed / consistent).  Stated tolerances: positions 1e-11 relative (the
+Cholesky factor is unique only to rounding), tempered logL 2e-11 relative (FAST arithmetic, include/tamcmc_hip.h), move
+probabilities 1e-4 relative (exp of a difference of two ~1e5-sized log-posteriors)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NCH, LAM = 20, 1.3
+
+
+@pytest.fixture(scope="module")
+def c3(pkg, synth):
+    star = synth.make_c3_star(seed=20240229, nx=100000, step=0.02)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_STRICT)
+    ctx.set_spectrum(star.x, np.ones_like(star.x))
+    _, m0, _ = ctx.loglike_params_batch(star.model_id, star.params, star.plength, want_model=True)
+    star.set_spectrum_from_model(m0[0], seed=20240301)
+    ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, star.y)
+    yield star, ctx
+    ctx.close()
+
+
+def _full_state(star, s):
+    st = s.state()
+    params = np.tile(star.params, (NCH, 1))
+    params[:, star.index_to_relax] = st["vars"]
+    return dict(params=params, vars=st["vars"], logL=st["logL"], logPrior=st["logPrior"], logPost=st["logPost"]), st
+
+
+def _one_iteration_against_oracle(oracle, star, s, init_logL, learn, literal, c0):
+    before, raw = _full_state(star, s)
+    law = s.proposal_law()
+    it = raw["iteration"]
+    z, u, u_swap, ind_A = s.draws(it)
+    do_swap = it != 0                                   # dN_mixing = 1 (MALA.cpp:688)
+    T = LAM ** np.arange(NCH)
+    exp, law2, rc = oracle.sampler_iteration(star, star.y, T, init_logL, before, law, i=it, z=z, u_mh=u, learn=learn, do_swap=do_swap, ind_A=ind_A,
+                                             u_swap=u_swap, literal_444=literal, c0=c0)
+    assert rc == 0
+    smp, stt = s.run(1, stats=True)
+    after, raw2 = _full_state(star, s)
+    assert raw2["iteration"] == it + 1
+    assert np.allclose(after["vars"], exp["vars"], rtol=1e-11, atol=1e-13), np.max(np.abs(after["vars"] - exp["vars"]))
+    assert np.array_equal(smp[0], after["vars"])                                         # the recorded sample IS the state after the swap step
+    assert np.allclose(after["logL"], exp["logL"], rtol=2e-11, atol=0)
+    assert np.allclose(after["logPrior"], exp["logPrior"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(after["logPost"], exp["logPost"], rtol=2e-11, atol=0)
+    assert np.allclose(stt[0][:, 0], exp["logL"], rtol=2e-11) and np.allclose(stt[0][:, 2], exp["logPost"], rtol=2e-11)
+    assert np.allclose(raw2["Pmove"], exp["Pmove"], rtol=1e-4, atol=1e-300)
+    if learn:
+        mu, cov, sig = s.proposal_law()
+        assert np.allclose(mu, law2[0], rtol=1e-11, atol=1e-13) and np.allclose(sig, law2[2], rtol=1e-9)
+        assert np.allclose(cov, law2[1], rtol=1e-9, atol=1e-9 * np.abs(law2[1]).max())
+    return exp, ind_A, u_swap
+
+
+def _find_iteration(s, start, want_A, u_lo, u_hi):
+    for k in range(start, start + 20000):
+        _, _, us, ia = s.draws(k)
+        if ia == want_A and u_lo <= us <= u_hi:
+            return k
+    raise AssertionError("no such iteration")
+
+
+@pytest.mark.parametrize("engine", ["host", "device"])
+@pytest.mark.parametrize("swap_rule", [0, 1])
+def test_one_iteration_equals_the_oracle_at_the_headline_shape(pkg, oracle, c3, engine, swap_rule):
+    star, ctx = c3
+    c0 = 2.0
+    s = pkg.Sampler(ctx, star, nchains=NCH, lambda_temp=LAM, engine=engine, seed=77, Nt_learn=(10, 40), periods_learn=(1,), dN_mixing=1, c0=c0,
+                    swap_rule=swap_rule)
+    assert s.nvars == 93 and star.params.size == 111 and star.x.size == 100000
+    init_logL = s.state()["logL"].copy()                # Model_def's init_logLikelihood (model_def.cpp:142-150): the start point's
+    swaps_seen = {"in": 0, "across": 0, "refused": 0}
+    quirk_visible = 0
+
+    def note(exp, ind_A):
+        nonlocal quirk_visible
+        if exp["swapped"]:
+            swaps_seen["across" if ind_A == NCH // 2 - 1 else "in"] += 1
+        else:
+            swaps_seen["refused"] += 1
+
+    # (1) from the start point, no adaptation yet (iterations 0..2: iteration 0 has no swap step)
+    for _ in range(3):
+        exp, ia, _ = _one_iteration_against_oracle(oracle, star, s, init_logL, learn=False, literal=bool(swap_rule), c0=c0)
+        note(exp, ia)
+    s.run(7, record=False)                              # iterations 3..9
+    # (2) with adaptation (iterations 10..39 learn): two checked steps, then let it adapt
+    for _ in range(2):
+        exp, ia, _ = _one_iteration_against_oracle(oracle, star, s, init_logL, learn=True, literal=bool(swap_rule), c0=c0)
+        note(exp, ia)
+    s.run(28, record=False)                             # iterations 12..39: the proposal law is adapted now
+    assert s.state()["iteration"] == 40
+    # (3) settled chains, no adaptation: a swap pair inside a chain group, the pair that straddles the two groups (chains 9 | 10), each
+    #     with a comparator that accepts and one that refuses
+    vars_now = s.state()["vars"]
+    for want_A, (u_lo, u_hi) in ((3, (0.0, 0.02)), (NCH // 2 - 1, (0.0, 0.02)), (NCH // 2 - 1, (0.999, 1.0)), (14, (0.999, 1.0))):
+        k = _find_iteration(s, 1000, want_A, u_lo, u_hi)
+        s.set_state(vars_now, iteration=k)
+        exp, ia, us = _one_iteration_against_oracle(oracle, star, s, init_logL, learn=False, literal=bool(swap_rule), c0=c0)
+        assert ia == want_A
+        note(exp, ia)
+        if exp["swapped"]:
+            # the two rules differ by (prior_A - prior_B) in chain B's stored posterior
+            B = ia + 1
+            quirk_visible += int(abs(exp["logPost"][B] - (exp["logL"][B] + exp["logPrior"][B])) > 1e-9)
+        vars_now = s.state()["vars"]
+    assert swaps_seen["in"] >= 1 and swaps_seen["across"] >= 1 and swaps_seen["refused"] >= 1, swaps_seen
+    assert (quirk_visible >= 1) == (swap_rule == 1)     # rule 0 stores logL + logPrior; rule 1 keeps B's old prior in the sum
+    s.close()

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()
+# the phase-skip mask exists in the PROBE build only (`make -C tamcmc-c_amd probe`); the product library has no such code path
+pkg.LIB_PATH = os.path.join(ROOT, "tamcmc-c_amd", "libtamcmc_hip_probe.so")
+assert os.path.exists(pkg.LIB_PATH), "build it first: make -C tamcmc-c_amd probe"
 from tamcmc_c_amd import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 star = synth.make_c3_star()
