@@ -61,11 +61,11 @@ struct AcceptOut {
 // MALA.cpp:490-551 for one chain, by ONE lane: S = sum of the chain's per-tile partials, (logPr, status) = the proposal's prior and
 // table status, logPost_cur / logL_cur / logPr_cur = what the chain holds.  The same statement sequence serves both launch schemes.
 __device__ __forceinline__ AcceptOut mh_outcome(const DevSamplerArgs &a, int j, long itp, double S, double logPr, int status, double logL_cur,
-                                                double logPr_cur, double logPost_cur) {
-    double logL = (-(double)a.pl * S) / a.Tcoefs[j];  // call_likelihood, model_def.cpp:399-401
+                                                double logPr_cur, double logPost_cur, double Tcoef, double init_logL) {
+    double logL = (-(double)a.pl * S) / Tcoef;  // call_likelihood, model_def.cpp:399-401
     double logPost;
     if (status != TAMCMC_OK) logL = NAN;
-    if (logPr == -INFINITY || isnan(logPr)) { logL = a.init_logL[j]; logPost = -INFINITY; }  // model_def.cpp:476-480
+    if (logPr == -INFINITY || isnan(logPr)) { logL = init_logL; logPost = -INFINITY; }  // model_def.cpp:476-480
     else logPost = logL + logPr;
     double u, u1;
     rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)j, (uint64_t)itp, 0, u, u1);
@@ -111,29 +111,53 @@ __device__ void accept_result(const DevSamplerArgs &a, int j, long itp, int P, d
         for (int w = 1; w < TB / 64; w++) { t1 = t1 + s_red[2 * w]; t2 = t2 + s_red[2 * w + 1]; }
         const int C = a.C;
         *s_out = mh_outcome(a, j, itp, t1 + t2, a.logPr_prop[P * C + j], a.status_prop[P * C + j], a.logL_cur[P * C + j], a.logPr_cur[P * C + j],
-                            a.logPost_cur[P * C + j]);
+                            a.logPost_cur[P * C + j], a.Tcoefs[j], a.init_logL[j]);
     }
     __syncthreads();
 }
 
+// Data exchanged between workgroups of ONE launch (the tiles' partial sums, the swap pair's outcomes) goes through device-scope
+// accesses that bypass the per-XCD L2 (MI355X: eight L2s, not coherent with each other for ordinary loads/stores).  A full
+// __threadfence() per tile would write back and invalidate the XCD's whole L2 -- including the resident spectrum -- 4000 times per launch.
+__device__ __forceinline__ double coherent_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every earlier memory operation of this wave has completed (write-through stores have reached memory) before anything later issues
+__device__ __forceinline__ void drain_memory_ops() {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
 // (A): the same sum by ONE wave, in k_finalize's order: 256 strided per-thread sums (four per lane here), shuffle tree per 64, the
-// four in order.  Every lane returns the total.
+// four in order.  Every lane returns the total.  (device-scope loads: the partials were written by other workgroups of this launch)
 __device__ __forceinline__ double wave_partial_sum(const double *base, int ntiles) {
     const int lane = threadIdx.x & 63;
-    double t1 = 0, t2 = 0;
-    for (int q = 0; q < TB / 64; q++) {
-        double s1 = 0, s2 = 0;
-        for (int t = q * 64 + lane; t < ntiles; t += TB) {
-            s1 = s1 + base[2 * t];
-            s2 = s2 + base[2 * t + 1];
+    double s1[TB / 64], s2[TB / 64];
+#pragma unroll
+    for (int q = 0; q < TB / 64; q++) { s1[q] = 0; s2[q] = 0; }
+    for (int t0 = 0; t0 < ntiles; t0 += TB) {  // virtual thread q*64+lane of k_finalize adds tile t0 + q*64 + lane in this round
+        double v1[TB / 64], v2[TB / 64];
+#pragma unroll
+        for (int q = 0; q < TB / 64; q++) {  // the round's loads first: one memory round trip instead of four
+            const int t = t0 + q * 64 + lane;
+            v1[q] = t < ntiles ? coherent_load(base + 2 * t) : 0.0;
+            v2[q] = t < ntiles ? coherent_load(base + 2 * t + 1) : 0.0;
         }
 #pragma unroll
+        for (int q = 0; q < TB / 64; q++)
+            if (t0 + q * 64 + lane < ntiles) { s1[q] = s1[q] + v1[q]; s2[q] = s2[q] + v2[q]; }
+    }
+    double t1 = 0, t2 = 0;
+#pragma unroll
+    for (int q = 0; q < TB / 64; q++) {
+        double a1 = s1[q], a2 = s2[q];
+#pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            s1 = s1 + __shfl_down(s1, off, 64);
-            s2 = s2 + __shfl_down(s2, off, 64);
+            a1 = a1 + __shfl_down(a1, off, 64);
+            a2 = a2 + __shfl_down(a2, off, 64);
         }
-        if (q == 0) { t1 = s1; t2 = s2; }
-        else { t1 = t1 + s1; t2 = t2 + s2; }
+        if (q == 0) { t1 = a1; t2 = a2; }
+        else { t1 = t1 + a1; t2 = t2 + a2; }
     }
     return __shfl(t1 + t2, 0, 64);
 }
@@ -229,6 +253,30 @@ __device__ __forceinline__ double Lz_row(const DevSamplerArgs &a, int chain, int
     double s = 0;
     for (int k = 0; k <= i; k++) s = s + LT[(size_t)k * a.Nv + i] * s_z[k];
     return s;
+}
+
+// The same rows of L z with the loads of a batch issued before the first use (a row's sum stays in ascending k, the order of Lz_row):
+// lane i owns rows i and i+64.  A wave on its own has no other wave's loads to hide behind.
+__device__ __forceinline__ void Lz_rows_wave(const DevSamplerArgs &a, int chain, const double *s_z, double *out) {
+    constexpr int NB = 8;
+    const int Nv = a.Nv, lane = threadIdx.x;
+    const double *LT = a.LT + (size_t)chain * Nv * Nv;
+#pragma clang loop unroll(disable)
+    for (int i = lane; i < Nv; i += 64) {
+        double s = 0;
+        int k0 = 0;
+#pragma clang loop unroll(disable)
+        for (; k0 + NB <= i + 1; k0 += NB) {  // full batches: NB independent loads, then the NB terms in order
+            double l[NB];
+#pragma unroll
+            for (int u = 0; u < NB; u++) l[u] = LT[(size_t)(k0 + u) * Nv + i];
+#pragma unroll
+            for (int u = 0; u < NB; u++) s = s + l[u] * s_z[k0 + u];
+        }
+#pragma clang loop unroll(disable)
+        for (; k0 <= i; k0++) s = s + LT[(size_t)k0 * Nv + i] * s_z[k0];
+        out[i] = s;
+    }
 }
 
 // Proposal of iteration `it` for `chain` from the state in LDS (s_vars/s_params): x' = x + L z (MALA.cpp:348-355), L =
@@ -413,12 +461,36 @@ struct FusedArgs {
     double *noise;                     // [2][NS][stride]
     double *bg;                        // [2][NS][ntiles][8] or nullptr
     int *slot;                         // [2][C]   table slot of chain m's proposal at the iteration of that parity
-    unsigned *ticket;                  // [2][C]   tiles of chain m that have delivered their partial sums
+    double *lz;                        // [2][C][Nv] L z of chain m for the iteration of that parity, computed one launch ahead
+    unsigned *ticket;                  // [2][C][TK] two levels: [0] counts the chain's tile GROUPS that are complete, [1 + g] the tiles
+                                       //          of group g = tile mod NG that have delivered their partial sums; one 128-byte line
+                                       //          each (device-scope atomics on one line serialise in the memory-side atomic unit)
     unsigned *pair_ticket;             // [2]      chains of the swap pair that have done their MH test
-    AcceptOut *acc;                    // [2][C]   MH outcome of chain m (read by the partner that resolves the swap)
+    double *acc;                       // [2][C][5] MH outcome of chain m (acc, r, logL, logPr, logPost), read by the partner that resolves the swap
 };
 
-constexpr int ST_L = 1, ST_BR = 2, ST_ENTRY = 4;
+constexpr int ST_L = 1, ST_BR = 2, ST_ENTRY = 4, ST_LZ = 8;
+constexpr int NG = 8;                  // tile groups per chain (ticket level 1)
+constexpr int TKS = 32;                // unsigned per ticket line
+constexpr int TK = (1 + NG) * TKS;     // unsigned per chain
+
+// The scalar part of a chain's settled state (ONE lane): what it holds, the slot of its next proposal, the record of its statistics.
+__device__ __forceinline__ void fused_scalars(const DevSamplerArgs &a, const FusedArgs &f, int m, int src_acc, double src_r, const AcceptOut &o,
+                                              int next_slot, long it, int q, long rec) {
+    const int C = a.C, q1 = q ^ 1;
+    a.logL_cur[q1 * C + m] = o.logL;
+    a.logPr_cur[q1 * C + m] = o.logPr;
+    a.logPost_cur[q1 * C + m] = o.logPost;
+    f.slot[q1 * C + m] = next_slot;
+    a.moved[m] = src_acc;     // a swap exchanges the pair's moved / Pmove entries too (MALA.cpp:425-446)
+    a.Pmove[m] = src_r;
+    if (m == 0 && src_acc) a.counters[1] += 1;
+    if (m == 0) a.counters[0] = it + 1;
+    if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
+        double *r = a.stats + ((size_t)rec * C + m) * 3;
+        r[0] = o.logL; r[1] = o.logPr; r[2] = o.logPost;
+    }
+}
 
 // Writes chain m's settled state for the next iteration: position = chain `src`'s post-test position (its own, or the swap partner's),
 // scalars from `o` (already re-tempered after a swap); records the sample; names the slot of chain m's next proposal.
@@ -438,89 +510,146 @@ __device__ __forceinline__ void fused_finalize(const DevSamplerArgs &a, const Fu
     double *rv = (a.samples && rec >= 0) ? a.samples + ((size_t)rec * C + m) * Nv : nullptr;  // update_buffer_params (MALA.cpp:710)
     for (int i = lane; i < Nv; i += 64) { const double v = sv[i]; dv[i] = v; if (rv) rv[i] = v; }
     for (int i = lane; i < Np; i += 64) dp[i] = sp[i];
+    if (lane == 0) fused_scalars(a, f, m, src_acc, src_r, o, next_slot, it, q, rec);
+}
+
+// Chain m of the swap pair (A, A+1) has done its MH test (outcome in the arguments): publish it; the second of the two to get here
+// resolves the swap (MALA.cpp:397-461) and writes both chains' settled states.
+__device__ __attribute__((noinline)) void fused_settle_pair(const DevSamplerArgs *ga, const FusedArgs *gf, int m, int A, double u, int o_acc, double o_r,
+                                                            double o_logL, double o_logPr, double o_logPost, long it, int q, long rec) {
+    const DevSamplerArgs &a = *ga;
+    const FusedArgs &f = *gf;
+    const int lane = threadIdx.x, C = a.C;
+    AcceptOut o;
+    o.acc = o_acc; o.r = o_r; o.logL = o_logL; o.logPr = o_logPr; o.logPost = o_logPost;
     if (lane == 0) {
-        a.logL_cur[q1 * C + m] = o.logL;
-        a.logPr_cur[q1 * C + m] = o.logPr;
-        a.logPost_cur[q1 * C + m] = o.logPost;
-        f.slot[q1 * C + m] = next_slot;
-        a.moved[m] = src_acc;     // a swap exchanges the pair's moved / Pmove entries too (MALA.cpp:425-446)
-        a.Pmove[m] = src_r;
-        if (m == 0 && src_acc) a.counters[1] += 1;
-        if (m == 0) a.counters[0] = it + 1;
-        if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
-            double *r = a.stats + ((size_t)rec * C + m) * 3;
-            r[0] = o.logL; r[1] = o.logPr; r[2] = o.logPost;
+        double *w = f.acc + ((size_t)q * C + m) * 5;
+        coherent_store(w, (double)o.acc); coherent_store(w + 1, o.r); coherent_store(w + 2, o.logL); coherent_store(w + 3, o.logPr);
+        coherent_store(w + 4, o.logPost);
+    }
+    drain_memory_ops();
+    unsigned first = 0;
+    if (lane == 0) first = atomicAdd(&f.pair_ticket[q], 1u);
+    first = __shfl(first, 0, 64);
+    if (first == 0) return;  // the partner is still being evaluated: its last tile does the rest
+    const int partner = (m == A) ? A + 1 : A;
+    AcceptOut op = {0, 0., 0., 0., 0.};
+    if (lane == 0) {
+        const double *w = f.acc + ((size_t)q * C + partner) * 5;
+        op.acc = (int)coherent_load(w); op.r = coherent_load(w + 1); op.logL = coherent_load(w + 2); op.logPr = coherent_load(w + 3);
+        op.logPost = coherent_load(w + 4);
+    }
+    op.acc = __shfl(op.acc, 0, 64); op.r = __shfl(op.r, 0, 64);
+    op.logL = __shfl(op.logL, 0, 64); op.logPr = __shfl(op.logPr, 0, 64); op.logPost = __shfl(op.logPost, 0, 64);
+    AcceptOut oA = (m == A) ? o : op, oB = (m == A) ? op : o;
+    const int accA = oA.acc, accB = oB.acc;
+    const double rA = oA.r, rB = oB.r;
+    const int swapped = resolve_swap(a, A, u, oA, oB);
+    if (lane == 0) {
+        atomicAdd((unsigned long long *)&a.counters[2], 1ull);
+        if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
+    }
+    const int B = A + 1;
+    if (swapped) {  // each side continues from the other's post-test position: the extra candidate slots 2C .. 2C+3
+        fused_finalize(a, f, A, B, accB, rB, oA, 2 * C + accB, it, q, rec);
+        fused_finalize(a, f, B, A, accA, rA, oB, 2 * C + 2 + accA, it, q, rec);
+    } else {
+        fused_finalize(a, f, A, A, accA, rA, oA, 2 * A + accA, it, q, rec);
+        fused_finalize(a, f, B, B, accB, rB, oB, 2 * B + accB, it, q, rec);
+    }
+}
+
+// The chain's settle step, run by the wave of the chain's LAST tile (a real function call with pointer arguments, like the candidate
+// roles: inlined into the tile body it would raise the kernel's register allocation above three waves per SIMD).
+__device__ __attribute__((noinline)) void fused_settle(const DevSamplerArgs *ga, const FusedArgs *gf, int m, int ps, long it, int q, long rec) {
+    const DevSamplerArgs &a = *ga;
+    const FusedArgs &f = *gf;
+    const int lane = threadIdx.x, C = a.C, Nv = a.Nv, Np = a.desc.Np;
+    // Everything that does not depend on the sums is requested first (this wave is the launch's critical tail): the proposal's prior and
+    // status, what the chain holds, and BOTH vectors the chain may continue from (its position and its proposal).
+    // (ps = the slot of the chain's proposal: the tile that calls knows it, no load needed to find the proposal's data)
+    int stP = 0, stR = 0;
+    double c_logPr = 0, h_logL = 0, h_logPr = 0, h_logPost = 0, Tm = 1, il = 0;
+    if (lane == 0) {
+        stP = f.cand_stP[q * f.NS + ps]; stR = f.cand_stR[q * f.NS + ps]; c_logPr = f.cand_logPr[q * f.NS + ps];
+        h_logL = a.logL_cur[q * C + m]; h_logPr = a.logPr_cur[q * C + m]; h_logPost = a.logPost_cur[q * C + m];
+        Tm = a.Tcoefs[m]; il = a.init_logL[m];
+    }
+    constexpr int ME = 2;  // vector elements per lane held in registers (longer vectors take the generic copy)
+    const bool in_regs = Nv <= 64 * ME && Np <= 64 * ME;
+    double r_pv[ME], r_cv[ME], r_pp[ME], r_cp[ME];
+    if (in_regs) {
+        const double *pv = f.cand_vars + ((size_t)q * f.NS + ps) * Nv, *pp = f.cand_params + ((size_t)q * f.NS + ps) * Np;
+        const double *cv = a.vars_cur + ((size_t)q * C + m) * Nv, *cp = a.params_cur + ((size_t)q * C + m) * Np;
+#pragma unroll
+        for (int e = 0; e < ME; e++) {
+            const int i = lane + 64 * e;
+            r_pv[e] = i < Nv ? pv[i] : 0.0; r_cv[e] = i < Nv ? cv[i] : 0.0;
+            r_pp[e] = i < Np ? pp[i] : 0.0; r_cp[e] = i < Np ? cp[i] : 0.0;
         }
     }
+    // ---- the chain's MH test (MALA.cpp:490-551)
+    const double S = wave_partial_sum(a.partials + (size_t)m * a.ntiles * 2, a.ntiles);
+    AcceptOut o = {0, 0., 0., 0., 0.};
+    if (lane == 0) o = mh_outcome(a, m, it, S, c_logPr, stP != TAMCMC_OK ? stP : stR, h_logL, h_logPr, h_logPost, Tm, il);
+    o.acc = __shfl(o.acc, 0, 64); o.r = __shfl(o.r, 0, 64);
+    o.logL = __shfl(o.logL, 0, 64); o.logPr = __shfl(o.logPr, 0, 64); o.logPost = __shfl(o.logPost, 0, 64);
+    // ---- parallel tempering (MALA.cpp:397-461): the second chain of the pair to get here resolves the swap for both
+    int A = -1;
+    double u = 0;
+    if (is_swap_iter(a, it)) A = swap_first(a, it, &u);
+    if (A < 0 || (m != A && m != A + 1)) {  // not in the swap pair (or no swap step at this iteration)
+        if (!in_regs) { fused_finalize(a, f, m, m, o.acc, o.r, o, 2 * m + o.acc, it, q, rec); return; }
+        // the chain keeps its own position or takes its own proposal: both are in registers
+        const int q1 = q ^ 1;
+        double *dv = a.vars_cur + ((size_t)q1 * C + m) * Nv, *dp = a.params_cur + ((size_t)q1 * C + m) * Np;
+        double *rv = (a.samples && rec >= 0) ? a.samples + ((size_t)rec * C + m) * Nv : nullptr;  // update_buffer_params (MALA.cpp:710)
+#pragma unroll
+        for (int e = 0; e < ME; e++) {
+            const int i = lane + 64 * e;
+            if (i < Nv) { const double v = o.acc ? r_pv[e] : r_cv[e]; dv[i] = v; if (rv) rv[i] = v; }
+            if (i < Np) dp[i] = o.acc ? r_pp[e] : r_cp[e];
+        }
+        if (lane == 0) fused_scalars(a, f, m, o.acc, o.r, o, 2 * m + o.acc, it, q, rec);
+        return;
+    }
+    fused_settle_pair(ga, gf, m, A, u, o.acc, o.r, o.logL, o.logPr, o.logPost, it, q, rec);
 }
 
 // Tail of the likelihood tiles of the fused step: every tile's wave calls it once its partial sums are written.
 struct SettleTail {
     const DevSamplerArgs &a;
     const FusedArgs &f;
+    const DevSamplerArgs *ga;
+    const FusedArgs *gf;
     long it, rec;
     int q;
-    __device__ __forceinline__ void operator()(int m) const {
+    static constexpr bool coherent_partials = true;
+    __device__ __forceinline__ void operator()(int m, int tile, int ps) const {
         const int lane = threadIdx.x, C = a.C;
-        __threadfence();  // release: this tile's partial sums are visible device-wide before the ticket counts them
+        drain_memory_ops();  // this tile's two partial sums (write-through stores) are in memory before the ticket counts the tile
+        unsigned *tk = f.ticket + ((size_t)q * C + m) * TK;
+        const int g = tile % NG, in_group = (a.ntiles - g + NG - 1) / NG;  // tiles g, g+NG, ... < ntiles
         unsigned old = 0;
-        if (lane == 0) old = atomicAdd(&f.ticket[q * C + m], 1u);
+        if (lane == 0) {
+            old = atomicAdd(&tk[(1 + g) * TKS], 1u);
+            if (old == (unsigned)(in_group - 1)) old = atomicAdd(&tk[0], 1u) + 0x10000u;  // the group's last tile reports the group
+        }
         old = __shfl(old, 0, 64);
-        if (old != (unsigned)(a.ntiles - 1)) return;  // not the chain's last tile (wave-uniform)
-        __threadfence();  // acquire: the other tiles' partial sums
-        // ---- the chain's MH test (MALA.cpp:490-551)
-        const double S = wave_partial_sum(a.partials + (size_t)m * a.ntiles * 2, a.ntiles);
-        const int ps = f.slot[q * C + m] & 0xffff;
-        AcceptOut o = {0, 0., 0., 0., 0.};
-        if (lane == 0) {
-            const int stP = f.cand_stP[q * f.NS + ps], stR = f.cand_stR[q * f.NS + ps];
-            o = mh_outcome(a, m, it, S, f.cand_logPr[q * f.NS + ps], stP != TAMCMC_OK ? stP : stR, a.logL_cur[q * C + m], a.logPr_cur[q * C + m],
-                           a.logPost_cur[q * C + m]);
-        }
-        o.acc = __shfl(o.acc, 0, 64); o.r = __shfl(o.r, 0, 64);
-        o.logL = __shfl(o.logL, 0, 64); o.logPr = __shfl(o.logPr, 0, 64); o.logPost = __shfl(o.logPost, 0, 64);
-        // ---- parallel tempering (MALA.cpp:397-461): the second chain of the pair to get here resolves the swap for both
-        int A = -1;
-        double u = 0;
-        if (is_swap_iter(a, it)) A = swap_first(a, it, &u);
-        if (m != A && m != A + 1) {
-            fused_finalize(a, f, m, m, o.acc, o.r, o, 2 * m + o.acc, it, q, rec);
-            return;
-        }
-        if (lane == 0) f.acc[q * C + m] = o;
-        __threadfence();
-        unsigned first = 0;
-        if (lane == 0) first = atomicAdd(&f.pair_ticket[q], 1u);
-        first = __shfl(first, 0, 64);
-        if (first == 0) return;  // the partner is still being evaluated: its last tile does the rest
-        __threadfence();
-        const int partner = (m == A) ? A + 1 : A;
-        AcceptOut op = {0, 0., 0., 0., 0.};
-        if (lane == 0) op = f.acc[q * C + partner];
-        op.acc = __shfl(op.acc, 0, 64); op.r = __shfl(op.r, 0, 64);
-        op.logL = __shfl(op.logL, 0, 64); op.logPr = __shfl(op.logPr, 0, 64); op.logPost = __shfl(op.logPost, 0, 64);
-        AcceptOut oA = (m == A) ? o : op, oB = (m == A) ? op : o;
-        const int accA = oA.acc, accB = oB.acc;
-        const double rA = oA.r, rB = oB.r;
-        const int swapped = resolve_swap(a, A, u, oA, oB);
-        if (lane == 0) {
-            atomicAdd((unsigned long long *)&a.counters[2], 1ull);
-            if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
-        }
-        const int B = A + 1;
-        if (swapped) {  // each side continues from the other's post-test position: the extra candidate slots 2C .. 2C+3
-            fused_finalize(a, f, A, B, accB, rB, oA, 2 * C + accB, it, q, rec);
-            fused_finalize(a, f, B, A, accA, rA, oB, 2 * C + 2 + accA, it, q, rec);
-        } else {
-            fused_finalize(a, f, A, A, accA, rA, oA, 2 * A + accA, it, q, rec);
-            fused_finalize(a, f, B, B, accB, rB, oB, 2 * B + accB, it, q, rec);
-        }
+        const int ngroups = a.ntiles < NG ? a.ntiles : NG;
+        if (old != 0x10000u + (unsigned)(ngroups - 1)) return;  // not the chain's last tile (wave-uniform)
+        fused_settle(ga, gf, m, ps, it, q, rec);
     }
 };
 
 // The three kinds of work on one candidate (see candidate_role); the proposal vector is in LDS.
-__device__ __attribute__((noinline)) void role_prior(const DevSamplerArgs &a, const FusedArgs &f, size_t gs, const double *s_vars,
-                                                     const double *s_params, const UnpackLds &U) {
+// (They are real function calls -- see candidate_role -- so their arguments are pointers to the DEVICE-MEMORY copies of the argument
+// blocks: a reference to a kernel argument would have to be copied to the scratch stack first.)
+__device__ __attribute__((noinline)) void role_prior(const DevSamplerArgs *ga, const FusedArgs *gf, size_t gs, const double *s_vars,
+                                                     const double *s_params, const UnpackLds *Up) {
+    const DevSamplerArgs &a = *ga;
+    const FusedArgs &f = *gf;
+    const UnpackLds U = *Up;
     const int Nv = a.Nv, Np = a.desc.Np, tid = threadIdx.x;
     for (int i = tid; i < Nv; i += 64) f.cand_vars[gs * Nv + i] = s_vars[i];
     for (int i = tid; i < Np; i += 64) f.cand_params[gs * Np + i] = s_params[i];
@@ -534,8 +663,11 @@ __device__ __forceinline__ TablePtrs candidate_tables(const DevSamplerArgs &a, c
     T.bg = nullptr; T.ntiles = a.ntiles; T.tile_bins = a.tile_bins;
     return T;
 }
-__device__ __attribute__((noinline)) void role_rows(const DevSamplerArgs &a, const FusedArgs &f, int q_dst, int slot, size_t gs,
-                                                    const double *s_params, const UnpackLds &U) {
+__device__ __attribute__((noinline)) void role_rows(const DevSamplerArgs *ga, const FusedArgs *gf, int q_dst, int slot, size_t gs,
+                                                    const double *s_params, const UnpackLds *Up) {
+    const DevSamplerArgs &a = *ga;
+    const FusedArgs &f = *gf;
+    const UnpackLds U = *Up;
     if (threadIdx.x == 0) mt::shared_scalars_base(a.desc.model_id, s_params, a.desc.plength, *U.S);
     __syncthreads();
     const TablePtrs T = candidate_tables(a, f, q_dst);
@@ -544,8 +676,11 @@ __device__ __attribute__((noinline)) void role_rows(const DevSamplerArgs &a, con
     wg_unpack(a.desc, s_params, U, slot, T, true, false, false, true);
     if (threadIdx.x == 0) f.cand_stR[gs] = *U.status;
 }
-__device__ __attribute__((noinline)) void role_background(const DevSamplerArgs &a, const FusedArgs &f, int q_dst, int slot, int role,
-                                                          const double *s_params, const UnpackLds &U) {
+__device__ __attribute__((noinline)) void role_background(const DevSamplerArgs *ga, const FusedArgs *gf, int q_dst, int slot, int role,
+                                                          const double *s_params, const UnpackLds *Up) {
+    const DevSamplerArgs &a = *ga;
+    const FusedArgs &f = *gf;
+    const UnpackLds U = *Up;
     if (!f.bg) return;
     if (threadIdx.x == 0) mt::shared_scalars_base(a.desc.model_id, s_params, a.desc.plength, *U.S);
     __syncthreads();
@@ -555,12 +690,27 @@ __device__ __attribute__((noinline)) void role_background(const DevSamplerArgs &
     wg_bg_tiles(a.desc, s_params, U.S, slot, T, 0, 64, role == 2 ? 0 : half, role == 2 ? half : a.ntiles);
 }
 
+// L z of chain `m` for iteration `itn` into f.lz[parity q_dst] (same streams, same row sums as propose_common), one wave.
+// (two separate functions, like the candidate roles: each stays within the register budget of the tile path)
+__device__ __attribute__((noinline)) void lz_normals(const DevSamplerArgs *ga, long itn, int m, double *s_z) {
+    normals_into(*ga, m, itn, s_z);
+}
+__device__ __attribute__((noinline)) void lz_rows(const DevSamplerArgs *ga, const FusedArgs *gf, int q_dst, int m, const double *s_z) {
+    Lz_rows_wave(*ga, m, s_z, gf->lz + ((size_t)q_dst * ga->C + m) * ga->Nv);
+}
+__device__ __forceinline__ void lz_block(const DevSamplerArgs *ga, const FusedArgs *gf, long itn, int q_dst, int m, unsigned char *lds) {
+    double *s_z = (double *)lds;
+    lz_normals(ga, itn, m, s_z);
+    __syncthreads();
+    lz_rows(ga, gf, q_dst, m, s_z);
+}
+
 // One role of one candidate slot of iteration `itn`, by ONE wave.  Slot s < 2C: chain s/2, built on its current position (even) or
 // on its proposal of iteration itn-1 (odd); slots 2C..2C+3 (only when itn-1 swaps a pair A,B): chain A on B's two vectors, chain B on
 // A's two.  Roles: 0 = position + log-prior, 1 = table rows + noise row, 2 / 3 = background series of the lower / upper half of the
 // tiles.  Every role re-derives the proposal vector itself (no communication between the roles).
-__device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, long itn, int q_src, int q_dst, int slot, int role, bool entry,
-                               unsigned char *lds) {
+__device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, const DevSamplerArgs *ga, const FusedArgs *gf, long itn, int q_src,
+                               int q_dst, int slot, int role, bool entry, unsigned char *lds) {
     const int C = a.C, Nv = a.Nv, Np = a.desc.Np, tid = threadIdx.x;
     int m, src, on_prop;
     if (slot < 2 * C) { m = slot >> 1; src = m; on_prop = slot & 1; }
@@ -573,7 +723,7 @@ __device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, long
     }
     if (entry && on_prop) return;  // a stretch starts from settled chains: there is no pending proposal to build on
     if (role == 0 && slot < 2 * C && !on_prop && tid == 0) {  // housekeeping for the launch that evaluates these candidates
-        f.ticket[q_dst * C + m] = 0u;
+        for (int g = 0; g <= NG; g++) f.ticket[((size_t)q_dst * C + m) * TK + g * TKS] = 0u;
         if (m == 0) f.pair_ticket[q_dst] = 0u;
         if (entry) f.slot[q_dst * C + m] = 2 * m;
     }
@@ -581,6 +731,8 @@ __device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, long
     double *s_vars = s_params + Np;
     double *s_z = s_vars + Nv;
     const UnpackLds U = carve_unpack_lds((unsigned char *)(s_z + Nv + 1));
+    __shared__ UnpackLds s_U;  // handed to the role functions by address
+    if (tid == 0) s_U = U;
     const double *bv, *bp;
     if (on_prop) {
         const int ps = f.slot[q_src * C + src] & 0xffff;
@@ -592,61 +744,76 @@ __device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, long
     }
     for (int i = tid; i < Nv; i += 64) s_vars[i] = bv[i];
     for (int i = tid; i < Np; i += 64) s_params[i] = bp[i];
-    normals_into(a, m, itn, s_z);
+    const double *lz = f.lz + ((size_t)q_dst * C + m) * Nv;  // L z(itn) of chain m, computed one launch ahead (lz_block)
     unpack_begin(a.desc, U);  // (barrier)
-    for (int i = tid; i < Nv; i += 64) s_vars[i] = s_vars[i] + 0.0 + Lz_row(a, m, i, s_z);  // same expression as propose_common
+    for (int i = tid; i < Nv; i += 64) s_vars[i] = s_vars[i] + 0.0 + lz[i];  // same expression as propose_common
     __syncthreads();
     for (int k = tid; k < Nv; k += 64) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
     __syncthreads();
     const size_t gs = (size_t)q_dst * f.NS + slot;
     // (three separate functions: inlined side by side the roles' code raises the whole kernel's register allocation above the
     // three-waves-per-SIMD budget of the tile path)
-    if (role == 0) role_prior(a, f, gs, s_vars, s_params, U);
-    else if (role == 1) role_rows(a, f, q_dst, slot, gs, s_params, U);
-    else role_background(a, f, q_dst, slot, role, s_params, U);
+    if (role == 0) role_prior(ga, gf, gs, s_vars, s_params, &s_U);
+    else if (role == 1) role_rows(ga, gf, q_dst, slot, gs, s_params, &s_U);
+    else role_background(ga, gf, q_dst, slot, role, s_params, &s_U);
 }
 
-// Launch `it` of a fused stretch: [0, nbr) candidate roles of iteration it+1 (flags & ST_BR; at the entry of a stretch, ST_ENTRY:
-// of iteration `it` itself from the settled chains, and nothing else), then the likelihood tiles of iteration `it` (flags & ST_L).
+// Per-launch scalars of the fused step.
+struct StepCtl {
+    long it, rec, it_lz;   // iteration of the tiles / candidates; record index (-1: none); first iteration of the L z blocks
+    int q, flags;          // parity of iteration `it`; ST_* bits
+    int nbr, nlz;          // workgroups reserved for candidate roles / L z blocks (multiples of 8: keeps the tiles' XCD mapping)
+    int n_lz_live, q_lz;   // L z blocks that have work (chain e % C of iteration it_lz + e / C); parity of it_lz
+    const DevSamplerArgs *ga;  // device-memory copies of the first two kernel arguments (for the candidate roles' function calls)
+    const struct FusedArgs *gf;
+};
+
+// Launch `it` of a fused stretch: [0, nbr) candidate roles of iteration it+1 (ST_BR; at the entry of a stretch, ST_ENTRY: of iteration
+// `it` itself from the settled chains), [nbr, nbr+nlz) L z of later iterations (ST_LZ), then the likelihood tiles of iteration `it` (ST_L).
 #define TAMCMC_STEP_BODY                                                                                                      \
     __shared__ tile::TileLds<MODE, 64> lds;                                                                                  \
     const int id = (int)blockIdx.x;                                                                                          \
-    if (id < nbr) {                                                                                                          \
-        if (flags & ST_ENTRY) candidate_role(a, f, it, q, q, id >> 2, id & 3, true, (unsigned char *)&lds);                  \
-        else candidate_role(a, f, it + 1, q, q ^ 1, id >> 2, id & 3, false, (unsigned char *)&lds);                          \
+    if (id < c.nbr) {                                                                                                        \
+        if (c.flags & ST_ENTRY) candidate_role(a, f, c.ga, c.gf, c.it, c.q, c.q, id >> 2, id & 3, true, (unsigned char *)&lds); \
+        else if (c.flags & ST_BR)                                                                                            \
+            candidate_role(a, f, c.ga, c.gf, c.it + 1, c.q, c.q ^ 1, id >> 2, id & 3, false, (unsigned char *)&lds);           \
         return;                                                                                                              \
     }                                                                                                                        \
-    if (flags & ST_L) tile::loglike_tile<MODE, 64, K, false, false>(la, id - nbr, lds, SettleTail{a, f, it, rec, q});
+    if (id < c.nbr + c.nlz) {                                                                                                \
+        const int e = id - c.nbr;                                                                                            \
+        if (e < c.n_lz_live) lz_block(c.ga, c.gf, c.it_lz + e / a.C, (c.q_lz ^ (e / a.C)) & 1, e % a.C, (unsigned char *)&lds); \
+        return;                                                                                                              \
+    }                                                                                                                        \
+    if (c.flags & ST_L)                                                                                                      \
+        tile::loglike_tile<MODE, 64, K, false, false>(la, id - c.nbr - c.nlz, lds, SettleTail{a, f, c.ga, c.gf, c.it, c.rec, c.q});
 // The tile path of K <= 8 bins per lane fits 168 VGPRs = three waves per SIMD; the candidate roles (log-prior, series) would raise the
-// kernel's allocation above that, so the occupancy is pinned here (those roles may spill, they are off the critical path).
+// kernel's allocation above that, so the occupancy is pinned here (those roles are separate functions, see candidate_role).
 template <int MODE, int K>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_step(const DevSamplerArgs a, const FusedArgs f, const LoglikeArgs la,
-                                                                                      const long it, const int q, const long rec, const int flags,
-                                                                                      const int nbr) {
+                                                                                      const StepCtl c) {
     TAMCMC_STEP_BODY
 }
 template <int MODE, int K>
-__global__ void __launch_bounds__(64) k_step_wide(const DevSamplerArgs a, const FusedArgs f, const LoglikeArgs la, const long it, const int q,
-                                                 const long rec, const int flags, const int nbr) {
+__global__ void __launch_bounds__(64) k_step_wide(const DevSamplerArgs a, const FusedArgs f, const LoglikeArgs la, const StepCtl c) {
     TAMCMC_STEP_BODY
 }
 #undef TAMCMC_STEP_BODY
 
 template <int MODE>
-bool launch_step_k(int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la, long it, int q, long rec,
-                   int flags, int nbr) {
-    if (K == 4) hipLaunchKernelGGL((k_step<MODE, 4>), dim3(grid), dim3(64), 0, st, a, f, la, it, q, rec, flags, nbr);
-    else if (K == 8) hipLaunchKernelGGL((k_step<MODE, 8>), dim3(grid), dim3(64), 0, st, a, f, la, it, q, rec, flags, nbr);
-    else if (K == 16) hipLaunchKernelGGL((k_step_wide<MODE, 16>), dim3(grid), dim3(64), 0, st, a, f, la, it, q, rec, flags, nbr);
+bool launch_step_k(int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la, const StepCtl &c) {
+    if (K == 4) hipLaunchKernelGGL((k_step<MODE, 4>), dim3(grid), dim3(64), 0, st, a, f, la, c);
+    else if (K == 8) hipLaunchKernelGGL((k_step<MODE, 8>), dim3(grid), dim3(64), 0, st, a, f, la, c);
+    else if (K == 16) hipLaunchKernelGGL((k_step_wide<MODE, 16>), dim3(grid), dim3(64), 0, st, a, f, la, c);
     else return false;
     return true;
 }
-hipError_t launch_step(int mode, int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la, long it,
-                       int q, long rec, int flags, int nbr) {
+hipError_t launch_step(int mode, int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la,
+                       const StepCtl &c) {
+    if (grid <= 0) return hipSuccess;
     bool ok;
-    if (mode == TAMCMC_PRECISION_FAST) ok = launch_step_k<tile::M_FAST>(K, grid, st, a, f, la, it, q, rec, flags, nbr);
-    else if (mode == TAMCMC_PRECISION_FAST_DIRECT) ok = launch_step_k<tile::M_FAST_DIRECT>(K, grid, st, a, f, la, it, q, rec, flags, nbr);
-    else ok = launch_step_k<tile::M_STRICT>(K, grid, st, a, f, la, it, q, rec, flags, nbr);
+    if (mode == TAMCMC_PRECISION_FAST) ok = launch_step_k<tile::M_FAST>(K, grid, st, a, f, la, c);
+    else if (mode == TAMCMC_PRECISION_FAST_DIRECT) ok = launch_step_k<tile::M_FAST_DIRECT>(K, grid, st, a, f, la, c);
+    else ok = launch_step_k<tile::M_STRICT>(K, grid, st, a, f, la, c);
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 
@@ -669,6 +836,8 @@ struct DevSampler::Impl {
     // overlaps the other groups' k_loglike (an iteration is a serial k_iterate -> k_loglike chain per group)
     bool pre_lz = true;  // (B): spare workgroups compute L z one iteration ahead while L is frozen
     FusedArgs f{};       // (A): candidate slots, tickets
+    unsigned char *d_argcopy = nullptr;  // device image of {DevSamplerArgs, FusedArgs} as last launched, and its host shadow
+    std::vector<unsigned char> h_argcopy;
     bool fused_ok = false;
     int fused_mode = -1, fused_K = 0;  // the geometry the (A) buffers were sized for
     int tile_rot = 0;  // launch-order hint of k_loglike (first near-field tile of chain 0's initial table)
@@ -801,7 +970,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
         DCHK(I.dalloc(&f.cand_stP, 2 * NS)); DCHK(I.dalloc(&f.cand_stR, 2 * NS));
         DCHK(I.dalloc(&f.mults, 2 * NS * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&f.pairs, 4 * NS)); DCHK(I.dalloc(&f.nh, 2 * NS)); DCHK(I.dalloc(&f.nn, 2 * NS));
         DCHK(I.dalloc(&f.noise, 2 * NS * (size_t)a.desc.stride));
-        DCHK(I.dalloc(&f.slot, 2 * C)); DCHK(I.dalloc(&f.ticket, 2 * C)); DCHK(I.dalloc(&f.pair_ticket, 2)); DCHK(I.dalloc(&f.acc, 2 * C));
+        DCHK(I.dalloc(&f.slot, 2 * C)); DCHK(I.dalloc(&f.ticket, 2 * C * TK)); DCHK(I.dalloc(&f.lz, 2 * C * Nv)); DCHK(I.dalloc(&f.pair_ticket, 2)); DCHK(I.dalloc(&f.acc, 2 * C * 5));
         DCHK(hipMemsetAsync(f.nn, 0, 2 * NS * sizeof(int), st));
         DCHK(hipMemsetAsync(f.cand_stP, 0, 2 * NS * sizeof(int), st));
         DCHK(hipMemsetAsync(f.cand_stR, 0, 2 * NS * sizeof(int), st));
@@ -1085,20 +1254,49 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     auto fused = [&](long ia, long ib) -> int {
         const FusedArgs &f = I.f;
         const int nbr = 4 * f.NS;                                     // candidate roles, a multiple of 8 (keeps the tiles' XCD mapping)
+        const int nlz1 = ((a.C + 7) / 8) * 8, nlz2 = ((2 * a.C + 7) / 8) * 8;
         const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
         const int grid_tiles = ntiles_pad * a.C;
         const long len = ib - ia;
         const long ev_every = len > 32 ? len / 32 : 1;
         int q = P;
-        // entry: the candidates of iteration ia, built on the settled chains (state of parity q)
-        DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[q], it0 + ia, q, -1, ST_ENTRY, nbr));
+        StepCtl sc{};
+        {  // device-memory image of the two argument blocks (re-uploaded only when a pointer or size changed since the last run)
+            const size_t n1 = (sizeof(DevSamplerArgs) + 15) & ~(size_t)15, n2 = sizeof(FusedArgs);
+            std::vector<unsigned char> img(n1 + n2, 0);
+            std::memcpy(img.data(), &args, sizeof(DevSamplerArgs));
+            std::memcpy(img.data() + n1, &f, sizeof(FusedArgs));
+            if (!I.d_argcopy) DCHK(I.dalloc(&I.d_argcopy, n1 + n2));
+            if (img != I.h_argcopy) {
+                DCHK(hipMemcpyAsync(I.d_argcopy, img.data(), n1 + n2, hipMemcpyHostToDevice, st));
+                DCHK(hipStreamSynchronize(st));  // (img is a stack object)
+                I.h_argcopy = img;
+            }
+            sc.ga = (const DevSamplerArgs *)I.d_argcopy;
+            sc.gf = (const FusedArgs *)(I.d_argcopy + n1);
+        }
+        // entry: L z of the first two iterations, then the candidates of iteration ia built on the settled chains (state of parity q)
+        sc.it = it0 + ia; sc.rec = -1; sc.q = q; sc.flags = ST_LZ; sc.nbr = 0; sc.nlz = nlz2; sc.n_lz_live = 2 * a.C; sc.it_lz = it0 + ia; sc.q_lz = q;
+        DCHK(launch_step(c->precision, c->K, nlz2, st, args, f, lf[q], sc));
+        sc.flags = ST_ENTRY; sc.nbr = nbr; sc.nlz = 0; sc.n_lz_live = 0;
+        DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[q], sc));
         for (long i = ia; i < ib; i++) {
-            const bool last = (i + 1 == ib);
-            const long rec = (samples || stats) ? i : (long)-1;
+            const bool last = (i + 1 == ib), lz_ahead = (i + 2 < ib);
+            sc.it = it0 + i; sc.rec = (samples || stats) ? i : (long)-1; sc.q = q;
+            sc.flags = ST_L | (last ? 0 : ST_BR) | (lz_ahead ? ST_LZ : 0);
+            sc.nbr = last ? 0 : nbr;
+            sc.nlz = lz_ahead ? nlz1 : 0; sc.n_lz_live = lz_ahead ? a.C : 0; sc.it_lz = it0 + i + 2; sc.q_lz = q;
             const bool timed = c->timing && ((i - ia) % ev_every == 0) && used_ev < I.n_ev;
             if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
-            DCHK(launch_step(c->precision, c->K, (last ? 0 : nbr) + grid_tiles, st, args, f, lf[q], it0 + i, q, rec, ST_L | (last ? 0 : ST_BR),
-                             last ? 0 : nbr));
+            LoglikeArgs lq = lf[q];
+            if (a.C >= 3 && a.dN_mixing > 0 && ((it0 + i) % a.dN_mixing == 0) && it0 + i != 0) {  // this iteration's swap pair leads the launch
+                double u, u2;
+                rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)(it0 + i), 0, u, u2);
+                int A = (int)(u2 * (double)(a.C - 1));
+                if (A > a.C - 2) A = a.C - 2;
+                lq.prio_b = A;
+            }
+            DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + grid_tiles, st, args, f, lq, sc));
             if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
             q ^= 1;
         }

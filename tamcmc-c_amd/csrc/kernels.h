@@ -22,6 +22,7 @@ struct LoglikeArgs {
     long *dbg = nullptr;  // phase stamps of one workgroup / per-workgroup timeline
 #endif
     int tile_rot = 0;     // tile dispatched first (launch order wraps around); any value in [0, ntiles) gives the same results
+    int prio_b = -1;      // >= 0: evaluations prio_b and prio_b+1 are dispatched first (B >= 3); results do not depend on it
     const int32_t *slot_map = nullptr;  // nullptr: evaluation b reads table slot b; else slot_map[b] & 0xffff (fused sampler step)
     const tamcmc_multiplet *mults;  // concatenated multiplet tables
     const int32_t *offsets;         // [2B] (begin,end) multiplet range per evaluation

@@ -223,7 +223,9 @@ struct __attribute__((aligned(16))) TileLds {
 };
 
 // One tile of one evaluation: table slot `sb` (its multiplets, noise row, background series), result row `b` (partials / model).
-template <int MODE, int WGS, int K, bool WRITE_MODEL, bool DELTA>
+// COH: the two partial sums are written through to memory (device-scope stores) because another workgroup of the SAME launch reads
+// them (the fused sampler step's settle tail); MI355X has one L2 per XCD and plain stores stay in the writer's.
+template <int MODE, int WGS, int K, bool WRITE_MODEL, bool DELTA, bool COH = false>
 __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int tile, const int b, const int sb, TileLds<MODE, WGS> &S) {
     constexpr bool FAST = (MODE != M_STRICT);
     static_assert(!DELTA || (FAST && !WRITE_MODEL), "DELTA launches are FAST-mode, logL-only");
@@ -595,8 +597,13 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     block_reduce<2, WGS>(s, s_red, out);
     if (tid == 0) {
         double *p = a.partials + ((size_t)b * a.ntiles + tile) * 2;
-        p[0] = out[0];
-        p[1] = out[1];
+        if (COH) {
+            __hip_atomic_store(p, out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p + 1, out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            p[0] = out[0];
+            p[1] = out[1];
+        }
     }
     KSTAMP(6);
 #ifdef TAMCMC_PROBE
@@ -612,7 +619,8 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
 
 // Tail hook of loglike_tile: called by every lane of every workgroup that owns a real tile, after its partial sums are in memory.
 struct NoTail {
-    __device__ __forceinline__ void operator()(int /*b*/) const {}
+    static constexpr bool coherent_partials = false;
+    __device__ __forceinline__ void operator()(int /*b*/, int /*tile*/, int /*slot*/) const {}
 };
 
 // Workgroup `id` of a launch over ntiles x B (tile, evaluation) pairs, XCD-aware: ids id, id+8, id+16, .. share an XCD (round-robin
@@ -621,18 +629,33 @@ struct NoTail {
 template <int MODE, int WGS, int K, bool WRITE_MODEL, bool DELTA, class Tail>
 __device__ __forceinline__ void loglike_tile(const LoglikeArgs &a, const int id, TileLds<MODE, WGS> &S, const Tail &tail) {
     const int xcd = id & 7;
-    const int j = id >> 3;
-    const int b = j % a.B;
+    int j = id >> 3, b, tile;
     // launch order = tile_rot, tile_rot+1, ..., wrapping: the caller points tile_rot at the first tile of the mode region so
     // that the long-running tiles (near field) are dispatched first and the cheap far-field-only tiles fill the tail
-    int tile = (j / a.B) * 8 + xcd;
+    if (a.prio_b < 0) {
+        b = j % a.B;
+        tile = (j / a.B) * 8 + xcd;
+    } else {
+        // evaluations prio_b and prio_b + 1 lead the launch (fused sampler step: the swap pair's settle is longer than the others';
+        // finishing first hides it behind the other chains' tiles); the rest follow in the usual tile-major order
+        const int lead = ((a.ntiles + 7) >> 3) * 2;  // (tile group, evaluation) pairs of the two leading evaluations
+        if (j < lead) {
+            b = a.prio_b + (j & 1);
+            tile = (j >> 1) * 8 + xcd;
+        } else {
+            j -= lead;
+            const int rest = a.B - 2, r = j % rest;
+            b = r + (r >= a.prio_b ? 2 : 0);
+            tile = (j / rest) * 8 + xcd;
+        }
+    }
     if (tile >= a.ntiles) return;  // padding workgroup: leaves before any barrier
     tile += a.tile_rot;
     if (tile >= a.ntiles) tile -= a.ntiles;
     const int sb = a.slot_map ? (a.slot_map[b] & 0xffff) : b;
     if (a.nnoise[sb] > 0)  // else: empty evaluation slot (a candidate that was not built, or whose table failed)
-        tile_compute<MODE, WGS, K, WRITE_MODEL, DELTA>(a, tile, b, sb, S);
-    tail(b);
+        tile_compute<MODE, WGS, K, WRITE_MODEL, DELTA, Tail::coherent_partials>(a, tile, b, sb, S);
+    tail(b, tile, sb);
 }
 
 }  // namespace tile
