@@ -838,6 +838,11 @@ struct DevSampler::Impl {
     FusedArgs f{};       // (A): candidate slots, tickets
     unsigned char *d_argcopy = nullptr;  // device image of {DevSamplerArgs, FusedArgs} as last launched, and its host shadow
     std::vector<unsigned char> h_argcopy;
+    // (A) carried over between run() calls: the last launch of a fused stretch also prepares the candidates of the iteration that
+    // follows and the L z of the one after; a call that continues right there starts without the two entry launches
+    long armed_it = -1;
+    int armed_q = 0;
+
     bool fused_ok = false;
     int fused_mode = -1, fused_K = 0;  // the geometry the (A) buffers were sized for
     int tile_rot = 0;  // launch-order hint of k_loglike (first near-field tile of chain 0's initial table)
@@ -986,6 +991,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
 int DevSampler::upload_state(const double *vars, const double *params, const double *logL, const double *logPr,
                              const double *logPost, const double *init_logL) {
     Impl &I = *impl;
+    I.armed_it = -1;
     tamcmc_hip_ctx *c = I.ctx;
     DevSamplerArgs &a = I.a;
     const size_t C = (size_t)a.C, Np = (size_t)a.desc.Np, Nv = (size_t)a.Nv;
@@ -1010,6 +1016,7 @@ int DevSampler::upload_state(const double *vars, const double *params, const dou
 
 int DevSampler::upload_proposal(int m, const double *L_rowmajor, const double *cov, const double *mu, double sigma) {
     Impl &I = *impl;
+    I.armed_it = -1;
     tamcmc_hip_ctx *c = I.ctx;
     DevSamplerArgs &a = I.a;
     const size_t Nv = (size_t)a.Nv;
@@ -1176,6 +1183,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
 
     // ---- (B) one iteration per round over [ia, ib): k_iterate settles iteration it-1 and proposes iteration it
     auto lockstep = [&](long ia, long ib) -> int {
+        I.armed_it = -1;
         // the extra streams start after everything already enqueued on the context stream
         if (G > 1) {
             DCHK(hipEventRecord(I.ev_fork, st));
@@ -1258,7 +1266,6 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
         const int grid_tiles = ntiles_pad * a.C;
         const long len = ib - ia;
-        const long ev_every = len > 32 ? len / 32 : 1;
         int q = P;
         StepCtl sc{};
         {  // device-memory image of the two argument blocks (re-uploaded only when a pointer or size changed since the last run)
@@ -1271,23 +1278,27 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
                 DCHK(hipMemcpyAsync(I.d_argcopy, img.data(), n1 + n2, hipMemcpyHostToDevice, st));
                 DCHK(hipStreamSynchronize(st));  // (img is a stack object)
                 I.h_argcopy = img;
+                I.armed_it = -1;                 // (the carried-over candidates were built for the old buffers)
             }
             sc.ga = (const DevSamplerArgs *)I.d_argcopy;
             sc.gf = (const FusedArgs *)(I.d_argcopy + n1);
         }
-        // entry: L z of the first two iterations, then the candidates of iteration ia built on the settled chains (state of parity q)
-        sc.it = it0 + ia; sc.rec = -1; sc.q = q; sc.flags = ST_LZ; sc.nbr = 0; sc.nlz = nlz2; sc.n_lz_live = 2 * a.C; sc.it_lz = it0 + ia; sc.q_lz = q;
-        DCHK(launch_step(c->precision, c->K, nlz2, st, args, f, lf[q], sc));
-        sc.flags = ST_ENTRY; sc.nbr = nbr; sc.nlz = 0; sc.n_lz_live = 0;
-        DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[q], sc));
+        if (!(I.armed_it == it0 + ia && I.armed_q == q)) {
+            // entry: L z of the first two iterations, then the candidates of iteration ia built on the settled chains (state of parity q)
+            sc.it = it0 + ia; sc.rec = -1; sc.q = q; sc.flags = ST_LZ; sc.nbr = 0; sc.nlz = nlz2; sc.n_lz_live = 2 * a.C; sc.it_lz = it0 + ia; sc.q_lz = q;
+            DCHK(launch_step(c->precision, c->K, nlz2, st, args, f, lf[q], sc));
+            sc.flags = ST_ENTRY; sc.nbr = nbr; sc.nlz = 0; sc.n_lz_live = 0;
+            DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[q], sc));
+        }
+        // the likelihood kernel's time for the roofline: two events around the whole stretch (launches back to back on one stream),
+        // i.e. the average includes the ~1.4 us between two launches
+        const bool timed = c->timing && used_ev < I.n_ev;
+        if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
         for (long i = ia; i < ib; i++) {
-            const bool last = (i + 1 == ib), lz_ahead = (i + 2 < ib);
+            // every launch also prepares the next iteration's candidates and the L z after that -- the last one too (see armed_it)
             sc.it = it0 + i; sc.rec = (samples || stats) ? i : (long)-1; sc.q = q;
-            sc.flags = ST_L | (last ? 0 : ST_BR) | (lz_ahead ? ST_LZ : 0);
-            sc.nbr = last ? 0 : nbr;
-            sc.nlz = lz_ahead ? nlz1 : 0; sc.n_lz_live = lz_ahead ? a.C : 0; sc.it_lz = it0 + i + 2; sc.q_lz = q;
-            const bool timed = c->timing && ((i - ia) % ev_every == 0) && used_ev < I.n_ev;
-            if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
+            sc.flags = ST_L | ST_BR | ST_LZ;
+            sc.nbr = nbr; sc.nlz = nlz1; sc.n_lz_live = a.C; sc.it_lz = it0 + i + 2; sc.q_lz = q;
             LoglikeArgs lq = lf[q];
             if (a.C >= 3 && a.dN_mixing > 0 && ((it0 + i) % a.dN_mixing == 0) && it0 + i != 0) {  // this iteration's swap pair leads the launch
                 double u, u2;
@@ -1297,13 +1308,20 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
                 lq.prio_b = A;
             }
             DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + grid_tiles, st, args, f, lq, sc));
-            if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
             q ^= 1;
         }
+        if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
         P = q;
-        if (c->timing) {
+        I.armed_it = it0 + ib;
+        I.armed_q = q;
+        if (timed) {
             DCHK(hipStreamSynchronize(st));
-            return drain_events((double)len, len * (long)a.C);
+            float ms = 0;
+            DCHK(hipEventElapsedTime(&ms, I.ev[used_ev - 1][0], I.ev[used_ev - 1][1]));
+            used_ev = 0;
+            kernel_ms += ms;
+            n_launch += len;
+            n_eval += len * (long)a.C;
         }
         return TAMCMC_OK;
     };

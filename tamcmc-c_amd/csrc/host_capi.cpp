@@ -26,7 +26,15 @@ struct tamcmc_sampler {
     long accepted0 = 0;
     tamcmc_hip_ctx *ctx = nullptr;  // borrowed
     bool attached = false;
+    // engine 1: the host mirrors (cur, mala's proposal law) are refreshed from the device only when somebody looks at them
+    mutable bool stale_state = false, stale_proposal = false;
     int sync_from_device(bool proposal_too);
+    int refresh() const {
+        if (!dev || (!stale_state && !stale_proposal)) return TAMCMC_OK;
+        const int rc = const_cast<tamcmc_sampler *>(this)->sync_from_device(stale_proposal);
+        if (rc == TAMCMC_OK) { stale_state = false; stale_proposal = false; }
+        return rc;
+    }
 };
 
 // pull the device engine's chain state (and, after learning, its proposal law) into the host mirrors
@@ -156,7 +164,9 @@ int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, doubl
         int rc = s->dev->run(it0, (long)n_iter, any ? learn.data() : nullptr, samples, stats);
         if (rc) return rc;
         s->mala->iteration = it0 + (long)n_iter;
-        return s->sync_from_device(any);
+        s->stale_state = true;                       // downloaded when a getter asks (tamcmc_sampler_get_state, ...)
+        s->stale_proposal = s->stale_proposal || any;
+        return TAMCMC_OK;
     }
     for (int64_t it = 0; it < n_iter; it++) {
         int rc = s->mala->step(s->cur.get(), s->prop.get(), &s->cfg.data.data, &s->cfg);
@@ -230,6 +240,7 @@ int tamcmc_sampler_draws(const tamcmc_sampler *s, int64_t iteration, double *z, 
 int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL, double *logPrior, double *logPost,
                              double *Pmove, double *sigma, int64_t *counters) {
     if (!s) return TAMCMC_ERR_BAD_ARG;
+    if (int rc = s->refresh()) return rc;
     const size_t Nc = (size_t)s->cfg.MALA.Nchains;
     if (vars) std::memcpy(vars, s->cur->vars.a.data(), s->cur->vars.a.size() * sizeof(double));
     if (logL) std::memcpy(logL, s->cur->logLikelihood.data(), Nc * sizeof(double));
@@ -248,6 +259,7 @@ int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL
 
 int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, double *covarmat) {
     if (!s || m < 0 || m >= s->cfg.MALA.Nchains) return TAMCMC_ERR_BAD_ARG;
+    if (int rc = s->refresh()) return rc;
     const long Nv = s->cur->get_Nvars();
     if (mu) std::memcpy(mu, s->mala->mu.row(m), (size_t)Nv * sizeof(double));
     if (covarmat) std::memcpy(covarmat, s->mala->covarmat[(size_t)m].a.data(), (size_t)(Nv * Nv) * sizeof(double));
@@ -256,6 +268,7 @@ int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, 
 
 int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, const double *covarmat, double sigma) {
     if (!s || m < 0 || m >= s->cfg.MALA.Nchains) return TAMCMC_ERR_BAD_ARG;
+    if (int rc = s->refresh()) return rc;
     const long Nv = s->cur->get_Nvars();
     if (mu) std::memcpy(s->mala->mu.row(m), mu, (size_t)Nv * sizeof(double));
     if (covarmat) std::memcpy(s->mala->covarmat[(size_t)m].a.data(), covarmat, (size_t)(Nv * Nv) * sizeof(double));
@@ -271,6 +284,7 @@ int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, 
 // Model_def constructor path of the reference, config.cpp:1734-1990, MALA.cpp:100-131).  Re-evaluates prior and likelihood.
 int tamcmc_sampler_set_state(tamcmc_sampler *s, const double *vars, int64_t iteration) {
     if (!s || !vars) return TAMCMC_ERR_BAD_ARG;
+    if (int rc = s->refresh()) return rc;  // (the proposal law and the counters stay what the device holds)
     const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
     for (long m = 0; m < Nc; m++) {
         std::memcpy(s->cur->vars.row(m), vars + (size_t)m * Nv, (size_t)Nv * sizeof(double));
@@ -290,6 +304,7 @@ int tamcmc_sampler_set_state(tamcmc_sampler *s, const double *vars, int64_t iter
 
 int tamcmc_sampler_write_restore(const tamcmc_sampler *s, const char *root, const char *const *var_names) {
     if (!s || !root) return TAMCMC_ERR_BAD_ARG;
+    if (int rc = s->refresh()) return rc;
     const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
     std::vector<double> mus((size_t)(Nc * Nv)), covs((size_t)(Nc * Nv * Nv));
     for (long m = 0; m < Nc; m++) {
