@@ -2,14 +2,18 @@
 """bench.py -- MCMC samples/s of the MI355X hot path on BASELINE.json's headline configuration.
 
 One "step" = one MCMC iteration of one star = ALL tempered chains advanced once
-(propose -> batched Lorentzian-sum model + chi^2(2 d.o.f.) log-likelihood on the GPU -> accept -> PT swap),
+(propose -> batched Lorentzian-sum model + chi^2(2 d.o.f.) log-likelihood on the GPU -> accept -> PT swap -> sample recorded),
 i.e. the reference's loop counter i (MALA.cpp:623,743).  Workload at N=1: configs[2] (C3) of BASELINE.json:
 global MS fit, model_MS_Global_aj_HarveyLike, 1e5 bins x 111 parameters (93 free) x 20 tempered chains, synthetic star.
 N>1 (torchrun, one rank per GPU): one independent star per GPU, no data-path collective (SURVEY 8e) -> weak scaling;
 torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
 
-The spectrum is resident in HBM before the timed region; per-step host->device traffic is the chains' mode tables
-(~170 KB) -- the boundary hands over host parameter vectors, like Model_def::generate_model does.
+Phases, like the reference's processing chain Burn-in -> Learning -> Acquire (Config/config_presets.cfg:26-31): the sampler's set-up
+runs a burn-in + learning stretch (adaptation of the proposal law on, untimed: it brings the chains and the proposal scales to
+the steady state and primes every launch pattern); then W warm-up and K timed iterations of the ACQUIRE phase (no adaptation).
+The timed region records the samples and the statistics of every iteration (MALA.cpp:706-716) and copies them back.
+
+The spectrum is resident in HBM before the timed region; the iteration itself runs on the device (no per-step host traffic).
 """
 import argparse
 import json
@@ -27,8 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6  # vector fp64
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_FMA_PEAK = 39.3e12          # vector fp64: 78.6 TFLOP/s spec = 39.3e12 fused multiply-adds per second
+SETUP_LEARN = (100, 1100)        # set-up phase: adaptation in iterations [100, 1100)
+SETUP_ITERS = 1500               # ... of SETUP_ITERS burn-in + learning iterations
 
 
 def parse():
@@ -45,7 +51,7 @@ def parse():
                     help="device = whole MCMC iteration resident on the GPU; host = host-driven loop (one device call per step)")
     ap.add_argument("--bins-per-thread", type=int, default=0, choices=[0, 1, 2, 4, 8, 16], help="tile = workgroup*K bins (0 = library default)")
     ap.add_argument("--workgroup", type=int, default=0, choices=[0, 64, 256], help="workgroup size of the likelihood kernel (0 = library default)")
-    ap.add_argument("--mala-steps", type=int, default=30, help="extra MALA-FD measurement (0 = skip)")
+    ap.add_argument("--mala-steps", type=int, default=60, help="extra MALA-FD measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--packed-stars", type=int, default=4,
@@ -58,12 +64,23 @@ def parse():
                     help="only the timed headline run (no packed / red-giant / MALA / launch-shape / CPU legs): the command profiled under "
                          "rocprofv3 for profiles/, so that the per-kernel averages are those of the headline launches")
     ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
+    ap.add_argument("--step-scheme", type=int, default=0, choices=[0, 1], help="device engine: 0 = fused one-launch iterations, 1 = lockstep kernels only")
     a = ap.parse_args()
     a.steps = max(a.steps, 1)
     a.warmup = max(a.warmup, 0)
     if a.headline_only:
         a.mala_steps, a.packed_stars, a.rgb_steps, a.no_cpu_baseline = 0, 0, 0, True
     return a
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(star, y, nchains, lam, budget_s):
@@ -87,20 +104,17 @@ def cpu_baseline(star, y, nchains, lam, budget_s):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 200:
             break
-    return {"value": n / el, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": n / el, "unit": "samples/s", "cores": cores, "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{n} batches of {nchains} chain evaluations (model_MS_Global_aj_HarveyLike + chi22p, Nx={star.x.size}) "
                       f"in {el:.1f} s; oracle/tamcmc_oracle.c -O3 -march=x86-64-v3, OpenMP over chains as MALA.cpp:648; "
                       "hot path only (no proposal/Cholesky/output cost), so it flatters the CPU"}
 
 
-def pmc_traffic():
-    """HBM bytes per k_loglike launch from the committed PMC passes (None if no profile has been committed)."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def committed_json(name):
     try:
-        d = json.load(open(p))
-        return d["hbm_bytes_per_launch"], d.get("launch", "")
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
-        return None, ""
+        return None
 
 
 def main():
@@ -137,6 +151,7 @@ def main():
     star = synth.make_c3_star(seed=20240229 + rank, nx=a.nx, step=2000.0 / a.nx)
     prec = pkg.PRECISION_FAST if a.precision == "fast" else pkg.PRECISION_STRICT
     ctx = pkg.HipContext(device_index, precision=prec, timing=True, bins_per_thread=a.bins_per_thread or None, workgroup=a.workgroup or None)
+    ctx.set_option(pkg.OPT_STEP_SCHEME, a.step_scheme)
     # synthetic spectrum y = M(theta_true) * Exp(1): the model row comes from the GPU path itself (STRICT arithmetic)
     ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_STRICT)
     ctx.set_spectrum(star.x, np.ones_like(star.x))
@@ -144,48 +159,81 @@ def main():
     y = star.set_spectrum_from_model(m0[0], seed=20240301 + rank)
     ctx.set_option(pkg.OPT_PRECISION, prec)
     ctx.set_spectrum(star.x, y)
+    T = lam ** np.arange(a.chains)
 
-    def make_sampler(use_drift, learn_until):
-        eng = "host" if use_drift else a.engine   # the Langevin drift runs on the host-driven engine
-        return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=eng,
-                           Nt_learn=((learn_until // 2, learn_until) if learn_until >= 2 else (10**9, 10**9 + 1)),  # adaptation ends inside the warm-up
-                           periods_learn=(1,), dN_mixing=a.dn_mixing)
+    def make_sampler(use_drift, engine):
+        return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=engine, Nt_learn=SETUP_LEARN,
+                           periods_learn=(1,), dN_mixing=a.dn_mixing, c0=2.0)
 
     from tamcmc_c_amd import shard
     mark("imports, library load, synthetic star, spectrum upload")
-    smp = make_sampler(1 if a.sampler == "mala" else 0, a.warmup)
-    smp.run(a.warmup, record=False)
-    mark("sampler set-up + warm-up steps")
+    use_drift = 1 if a.sampler == "mala" else 0
+    smp = make_sampler(use_drift, a.engine)
+    # ---- set-up phase (untimed): burn-in + learning; its last stretch already runs the acquire-phase launch pattern
+    smp.run(SETUP_ITERS if not use_drift else 150, record=False)
+    mark(f"sampler set-up: burn-in + learning phase ({SETUP_ITERS if not use_drift else 150} iterations, adaptation in {SETUP_LEARN})")
+    # record buffers the run() calls fill: the samples and the statistics of every iteration (page-locked, like a writer's ring buffer)
+    nrec = max(a.steps, a.warmup, 1)
+    buf_smp, buf_st = pkg.pinned_empty((nrec, a.chains, smp.nvars)), pkg.pinned_empty((nrec, a.chains, 3))
+    if a.warmup > 0:
+        smp.run(a.warmup, out=(buf_smp[:a.warmup], buf_st[:a.warmup]))
+    mark("warm-up steps")
     ctx.reset_kernel_stats()
     acc0 = smp.state()
     # barrier + synchronize on both sides, MAX over ranks (tests/test_multirank_gloo.py covers this on gloo)
-    elapsed, _ = shard.timed_region(lambda: smp.run(a.steps, record=False), dist=dist, sync=torch.cuda.synchronize)
+    elapsed, rec = shard.timed_region(lambda: smp.run(a.steps, out=(buf_smp[:a.steps], buf_st[:a.steps])), dist=dist, sync=torch.cuda.synchronize)
     k_ms, k_launches, k_evals = ctx.kernel_stats()
     st = smp.state()
     value = shard.aggregate_rate(a.steps, world, elapsed)
     mark("TIMED REGION (the K steps behind `value`), fences included")
 
+    # ---- end-to-end check of what the timed region left behind: the chains' tempered logL recomputed with STRICT arithmetic from the
+    # final positions (the recorded last sample), and the recorded statistics against the state
+    samples, stats = rec
+    Pfin = np.tile(star.params, (a.chains, 1))
+    Pfin[:, star.index_to_relax] = st["vars"]
+    ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_STRICT)
+    strict_logL, _, strict_status = ctx.loglike_params_batch(star.model_id, Pfin, star.plength, T)
+    ctx.set_option(pkg.OPT_PRECISION, prec)
+    end_err = float(np.max(np.abs(strict_logL - st["logL"]) / np.abs(strict_logL)))
+    assert (strict_status == 0).all() and end_err <= 1e-11, f"end-to-end check failed: {end_err}"
+    assert np.array_equal(samples[-1], st["vars"]) and np.array_equal(stats[-1][:, 0], st["logL"]), "recorded samples do not match the final state"
+    moved = np.mean(np.any(samples[1:] != samples[:-1], axis=2), axis=0) if a.steps > 1 else np.zeros(a.chains)
+    mark("end-to-end check (STRICT re-evaluation of the final states)")
+
     extra = {}
     if a.mala_steps > 0 and a.sampler == "mh" and world == 1:
-        ms = make_sampler(1, 10)
-        ms.run(5, record=False)
+        ms = make_sampler(1, "host")
+        ms.run(150, record=False)   # adaptation in [100, 150): the Langevin proposal needs its step size tuned
         ctx.reset_kernel_stats()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ms.run(a.mala_steps, record=False)
+        msmp, _ = ms.run(a.mala_steps, record=True)
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t1
         mk_ms, mk_l, mk_e = ctx.kernel_stats()
-        extra["mala_fd"] = {"samples_per_s": a.mala_steps / e1, "steps": a.mala_steps,
-                            "evals_per_step": mk_e / a.mala_steps, "kernel_us_per_launch": mk_ms / max(mk_l, 1) * 1e3,
-                            "alg_GBps": 16.0 * a.nx * mk_e / max(mk_ms * 1e-3, 1e-12) / 1e9}
+        fd_bins, fd_evals = ctx.fd_stats()
+        # bytes the FD launches touch: the C base evaluations read x, y and write the model row (24 B x Nx each); a delta evaluation
+        # reads x, y and the base model row on its affected range only (24 B per affected bin)
+        mala_bytes = 24.0 * a.nx * a.chains * mk_l + 24.0 * fd_bins
+        macc = np.mean(np.any(msmp[1:] != msmp[:-1], axis=2), axis=0) if a.mala_steps > 1 else np.zeros(a.chains)
+        extra["mala_fd"] = {"samples_per_s": a.mala_steps / e1, "steps": a.mala_steps, "evals_per_step": mk_e / a.mala_steps,
+                            "engine": "host-driven loop + device finite-difference batches (windowed delta tables)",
+                            "accept_rate_chain0": float(macc[0]), "accept_rate_mean": float(macc.mean()),
+                            "roofline": {"bound": "hbm", "kernel": "base k_loglike (model rows kept) + k_loglike<DELTA> per FD batch",
+                                         "kernel_us_per_batch": mk_ms / max(mk_l, 1) * 1e3,
+                                         "bytes_touched_per_batch": mala_bytes / max(mk_l, 1),
+                                         "mean_affected_bins_per_delta_evaluation": fd_bins / max(fd_evals, 1),
+                                         "achieved": mala_bytes / max(mk_ms * 1e-3, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": mala_bytes / max(mk_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                         "note": "bytes = 24 B x Nx per base evaluation + 24 B per bin of each delta evaluation's affected range "
+                                                 "(not 16 B x Nx per evaluation: a perturbed mode parameter changes the model inside its window only)"}}
         ms.close()
-
-    if extra:
         mark("extra leg: mala_fd")
+
     if a.packed_stars > 1 and a.sampler == "mh" and a.engine == "device" and world == 1:
         # Several independent stars on ONE GPU (one context + one device-resident sampler + one host thread per star,
-        # tamcmc_sampler_run_packed): a single star's iteration is two short dependent kernels, co-resident stars fill the idle SIMDs.
+        # tamcmc_sampler_run_packed): co-resident stars fill the SIMDs a single star's iteration leaves idle.
         from tamcmc_c_amd import sampler as smod
         pool = []
         for k in range(a.packed_stars):
@@ -197,25 +245,24 @@ def main():
             ck.set_option(pkg.OPT_PRECISION, prec)
             ck.set_spectrum(sk.x, yk)
             pool.append((ck, pkg.Sampler(ck, sk, nchains=a.chains, lambda_temp=lam, seed=107 + k, engine="device", chain_groups=1,
-                                         Nt_learn=((a.warmup // 2, a.warmup) if a.warmup >= 2 else (10**9, 10**9 + 1)), periods_learn=(1,), dN_mixing=a.dn_mixing)))
+                                         Nt_learn=SETUP_LEARN, periods_learn=(1,), dN_mixing=a.dn_mixing, c0=2.0)))
         ps = [q[1] for q in pool]
-        smod.run_packed(ps, a.warmup, record=False)
+        smod.run_packed(ps, SETUP_ITERS, record=False)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        smod.run_packed(ps, a.steps, record=False)
+        smod.run_packed(ps, a.steps, record=True, stats=True)
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t1
         rate = a.packed_stars * a.steps / e1
         extra["packed"] = {"stars_per_gpu": a.packed_stars, "samples_per_s": rate, "us_per_star_iteration": 1e6 * e1 / (a.steps * a.packed_stars),
                            "alg_GBps": rate * a.chains * 16.0 * a.nx / 1e9, "frac_of_hbm_peak": rate * a.chains * 16.0 * a.nx / 1e9 / HBM_PEAK_GBS,
-                           "note": "aggregate over the co-resident stars (each a full 20-chain C3 fit, one stream group per star); "
+                           "note": "aggregate over the co-resident stars (each a full 20-chain C3 fit on its own stream); "
                                    "every star's samples are bit-identical to its solo run (tests/test_gpu_sampler.py)"}
         for ck, sk_ in pool:
             sk_.close()
             ck.close()
+        mark("extra leg: packed (set-up of the co-resident stars + their learning phase + timed steps)")
 
-    if "packed" in extra:
-        mark("extra leg: packed (set-up of the co-resident stars + their warm-up + timed steps)")
     if a.rgb_steps > 0 and a.sampler == "mh" and world == 1:
         # BASELINE configs[4] family: red-giant star, mixed modes solved per proposal (csrc/rgb_prestep.hip), 40 tempered chains
         rs = synth.make_c5_star(nx=200000, nmax=10, dnu=10.0, bias_type=1, nferr=6)
@@ -224,29 +271,32 @@ def main():
         _, mr, _ = rc.loglike_params_batch(rs.model_id, rs.params, rs.plength, want_model=True)
         rs.set_spectrum_from_model(mr[0], 7)
         rc.set_spectrum(rs.x, rs.y)
-        rsmp = pkg.Sampler(rc, rs, nchains=40, lambda_temp=1.15, seed=5, engine="host", Nt_learn=(10, 100), periods_learn=(1,))
-        rsmp.run(100, record=False)
+        rsmp = pkg.Sampler(rc, rs, nchains=40, lambda_temp=1.15, seed=5, engine="host", Nt_learn=(10, 200), periods_learn=(1,))
+        rsmp.run(250, record=False)
         rc.reset_kernel_stats()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        rsmp.run(a.rgb_steps, record=False)
+        rsm, _ = rsmp.run(a.rgb_steps, record=True)
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t1
         r_ms, r_l, r_e = rc.kernel_stats()
+        racc = np.mean(np.any(rsm[1:] != rsm[:-1], axis=2), axis=0) if a.rgb_steps > 1 else np.zeros(40)
+        r_bytes = 16.0 * 200000 * r_e
         extra["c5_rgb"] = {"samples_per_s": a.rgb_steps / e1, "ms_per_step": 1e3 * e1 / a.rgb_steps, "steps": a.rgb_steps,
                            "workload": f"model_RGB_asympt_aj_AppWidth_HarveyLike_v4, Nx=200000, {rs.params.size} params ({rs.nvars} free), "
                                        "40 tempered chains, ~150 mixed modes per chain from the device ARMM solver; host-driven engine",
-                           "k_loglike_us_per_launch": r_ms / max(r_l, 1) * 1e3,
-                           "k_loglike_alg_GBps": 16.0 * 200000 * r_e / max(r_ms * 1e-3, 1e-12) / 1e9}
+                           "accept_rate_chain0": float(racc[0]), "accept_rate_mean": float(racc.mean()),
+                           "roofline": {"bound": "hbm", "kernel": "k_loglike (40 evaluations x 2e5 bins per launch; the pre-step kernels are not in this time)",
+                                        "kernel_us_per_launch": r_ms / max(r_l, 1) * 1e3, "evaluations_per_launch": r_e / max(r_l, 1),
+                                        "algorithmic_bytes_per_launch": r_bytes / max(r_l, 1), "achieved": r_bytes / max(r_ms * 1e-3, 1e-12) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_bytes / max(r_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS}}
         rsmp.close()
         rc.close()
-
-    if "c5_rgb" in extra:
         mark("extra leg: c5_rgb")
+
     shapes = []
     if world == 1 and a.sampler == "mh" and not a.headline_only:
-        # the same kernel at other launch sizes (standalone batched calls through the C ABI, live HIP-event timing): the sampler's
-        # launches above are small (one chain group), these show where the kernel goes with more evaluations per launch
+        # the likelihood kernel on its own at other launch sizes (standalone batched calls through the C ABI, live HIP-event timing)
         rng = np.random.default_rng(3)
         for Bs, reps in ((a.chains, 20), (10 * a.chains, 5)):
             Pm = np.tile(star.params, (Bs, 1))
@@ -258,8 +308,8 @@ def main():
                 ctx.loglike_params_batch(star.model_id, Pm, star.plength, Tm)
             s_ms, s_l, s_e = ctx.kernel_stats()
             us = s_ms / max(s_l, 1) * 1e3
-            shapes.append({"evaluations_per_launch": Bs, "kernel_us_per_launch": us, "achieved_GBps": 16.0 * a.nx * Bs / (us * 1e-6) / 1e9,
-                           "frac": 16.0 * a.nx * Bs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+            shapes.append({"kernel": "k_loglike (standalone)", "evaluations_per_launch": Bs, "kernel_us_per_launch": us,
+                           "achieved_GBps": 16.0 * a.nx * Bs / (us * 1e-6) / 1e9, "frac": 16.0 * a.nx * Bs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
 
     if rank == 0:
         st_tab, mults, _, _ = pkg.build_mode_table(star.model_id, star.params, star.plength, star.x)
@@ -268,6 +318,15 @@ def main():
         k_s = k_ms * 1e-3 / max(k_launches, 1)
         alg_bytes = 16.0 * a.nx * evals_per_launch          # B_eval = 16*Nx bytes per evaluation
         achieved = alg_bytes / k_s / 1e9
+        fused = (a.engine == "device" and a.sampler == "mh" and a.step_scheme == 0 and prec == pkg.PRECISION_FAST)
+        pmc = committed_json("r02_pmc_traffic.json") or {}
+        pmc_sq = committed_json("r02_pmc_sq.json") or {}
+        valu = None
+        if pmc_sq.get("SQ_INSTS_VALU_per_launch"):
+            # wave-level VALU instructions x 64 lanes / duration: an upper bound of the fp64 lane-operation rate (integer/address VALU included)
+            rate = pmc_sq["SQ_INSTS_VALU_per_launch"] * 64.0 / k_s
+            valu = {"valu_lane_ops_per_s": rate, "frac_of_fp64_fma_peak": rate / FP64_FMA_PEAK, "peak_fma_per_s": FP64_FMA_PEAK,
+                    "SQ_INSTS_VALU_per_launch": pmc_sq["SQ_INSTS_VALU_per_launch"], "source": "profiles/r02_pmc_sq.json (rocprofv3 --pmc, separate pass) x the live launch duration"}
         out = {
             "metric": "MCMC samples/sec (whole node), 1e5 nu-bins x 100 params x 20 tempered chains",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -277,27 +336,34 @@ def main():
                                    f"{len(mults)} multiplets, {a.chains} tempered chains (lambda={lam}), one star per GPU",
                        "sampler": "adaptive random-walk MH + parallel tempering (use_drift=0, the reference's sampler)"
                        if a.sampler == "mh" else "Langevin drift, forward-difference gradient (use_drift=1)",
-                       "engine": ("device-resident iteration (propose/prior/unpack/accept/swap kernels, no host round trip)"
+                       "engine": (("device-resident iteration, one fused launch per iteration (likelihood tiles + settle in their tail + next iteration's candidates)"
+                                   if fused else "device-resident iteration, lockstep kernels (k_iterate, k_loglike)")
                                   if (a.engine == "device" and a.sampler == "mh") else "host-driven loop"),
-                       "arithmetic": a.precision, "component_bin_evals_per_model": W},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic()[0], "traffic_unit": "bytes per launch",
-                         "traffic_source": "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                                           "passes, FETCH_SIZE x2 (gfx950; the guide calibrates the factor on 16 B/lane reads, this kernel reads 8 B/lane, so the "
-                                           "absolute is uncertain within that factor -- either way far below the algorithmic bytes: the spectrum is "
-                                           "served from L2), launch shape: " + pmc_traffic()[1] + "; not re-measured live",
-                         "kernel": "k_loglike",
+                       "phases": f"set-up: {SETUP_ITERS} burn-in + learning iterations with adaptation in {SETUP_LEARN} (untimed); then {a.warmup} warm-up + "
+                                 f"{a.steps} timed iterations of the acquire phase; samples and statistics of every timed iteration recorded and copied back",
+                       "arithmetic": a.precision, "component_bin_evals_per_model": W, "dN_mixing": a.dn_mixing},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_unit": "bytes per launch",
+                         "traffic_source": pmc.get("source", "no committed PMC pass for this kernel yet"),
+                         "kernel": "k_step<FAST, K=8> (fused step)" if fused else "k_loglike",
                          "kernel_us_per_launch": k_s * 1e6, "evaluations_per_launch": evals_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "launch_note": "the device sampler launches the chains as chain groups on separate streams (TAMCMC_CHAIN_GROUPS, "
-                                        "default 2): each timed launch carries evaluations_per_launch evaluations and overlaps the other "
-                                        "group's proposal kernel",
+                         "how_measured": ("two HIP events on the launch stream around each timed run() call's fused launches (back to back, one per "
+                                          "iteration): the average launch duration includes the ~1.4 us between two launches"
+                                          if fused else "HIP events around sampled k_loglike launches on their stream"),
+                         "by_survey_8d_definition": {"formula": "samples/s x bytes/sample / peak, bytes/sample = Nchains x 16 x Nx",
+                                                     "achieved": value / world * a.chains * 16.0 * a.nx / 1e9,
+                                                     "frac": value / world * a.chains * 16.0 * a.nx / 1e9 / HBM_PEAK_GBS},
+                         "valu": valu,
                          "other_launch_shapes": shapes,
                          "fp64_valu": {"component_evals_per_s": W * evals_per_launch / k_s,
                                        "note": "the path is fp64-VALU-bound (~110 Lorentzian components per 16 B); FAST mode folds far "
                                                "components into one polynomial per tile, so this is an EFFECTIVE rate"}},
             "accept_rate_chain0": (st["accepted0"] - acc0["accepted0"]) / max(a.steps, 1),
-            "swap_rate": st["swaps"] / max(st["swap_attempts"], 1),
+            "position_change_rate_mean": float(moved.mean()),
+            "swap_rate": (st["swaps"] - acc0["swaps"]) / max(st["swap_attempts"] - acc0["swap_attempts"], 1),
+            "end_to_end_check": {"max_rel_err_logL_final_states_vs_STRICT": end_err, "tolerance": 1e-11,
+                                 "recorded_last_sample_equals_state": True},
             "kernel_time_fraction": k_ms * 1e-3 / elapsed,
         }
         out.update(extra)

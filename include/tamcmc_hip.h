@@ -20,6 +20,7 @@
 #ifndef TAMCMC_HIP_H
 #define TAMCMC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -92,6 +93,11 @@ const char *tamcmc_hip_last_error(const tamcmc_hip_ctx *ctx);
 int tamcmc_hip_set_option(tamcmc_hip_ctx *ctx, int option, int64_t value);
 const char *tamcmc_hip_version(void);
 
+/* Page-locked host memory for buffers the library copies results into (recorded samples and statistics of tamcmc_sampler_run): any
+ * host pointer works there, a pinned one is filled by an asynchronous DMA instead of a staged copy.  NULL on failure. */
+void *tamcmc_hip_host_alloc(size_t bytes);
+void tamcmc_hip_host_free(void *p);
+
 /* Replaces the shared read-only `Data{x,y,Nx}` (tamcmc/headers/data.h:23-34) every chain reads:
  * uploads the spectrum once; it stays resident in HBM. x must be a regular grid (build_lorentzian.cpp:645). */
 int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *ctx, const double *x, const double *y, int64_t Nx);
@@ -158,6 +164,10 @@ int tamcmc_hip_fd_gradient_posterior(tamcmc_hip_ctx *ctx, int model_id, int prio
 int tamcmc_hip_get_kernel_stats(tamcmc_hip_ctx *ctx, double *kernel_ms_total, int64_t *launches,
                                 int64_t *evaluations);
 int tamcmc_hip_reset_kernel_stats(tamcmc_hip_ctx *ctx);
+/* Windowed finite differences (TAMCMC_OPT_FD_WINDOWED, timing enabled): since the last reset, the bins inside the affected ranges of
+ * the delta evaluations and the number of those evaluations -- the bytes such a launch really touches are 24 B per affected bin
+ * (x, y, base model row), not 16 B x Nx per evaluation. */
+int tamcmc_hip_get_fd_stats(tamcmc_hip_ctx *ctx, int64_t *affected_bins, int64_t *delta_evaluations);
 
 #ifdef __cplusplus
 }

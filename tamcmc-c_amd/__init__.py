@@ -48,6 +48,8 @@ ABI = [
     ("tamcmc_hip_destroy", None, [_vp]),
     ("tamcmc_hip_last_error", C.c_char_p, [_vp]),
     ("tamcmc_hip_set_option", C.c_int, [_vp, C.c_int, C.c_int64]),
+    ("tamcmc_hip_host_alloc", C.c_void_p, [C.c_size_t]),
+    ("tamcmc_hip_host_free", None, [_vp]),
     ("tamcmc_hip_set_spectrum", C.c_int, [_vp, _dp, _dp, C.c_int64]),
     ("tamcmc_hip_loglike_batch", C.c_int, [_vp, C.c_int, _vp, _ip, _dp, C.c_int, _ip, _ip, _dp, C.c_double, _dp, _dp]),
     ("tamcmc_build_mode_table", C.c_int, [C.c_int, _dp, _ip, _dp, C.c_int64, _vp, C.c_int, C.POINTER(C.c_int), _dp,
@@ -59,6 +61,7 @@ ABI = [
     ("tamcmc_hip_rgb_mixed_modes", C.c_int, [_vp, C.c_int, _dp, C.c_int64, _ip, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     ("tamcmc_hip_get_kernel_stats", C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("tamcmc_hip_reset_kernel_stats", C.c_int, [_vp]),
+    ("tamcmc_hip_get_fd_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
 
 _lib = None
@@ -98,6 +101,20 @@ def _i32(a):
 
 def _p(a, t=_dp):
     return a.ctypes.data_as(t) if a is not None else None
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A numpy array in page-locked host memory (tamcmc_hip_host_alloc): the record buffers of Sampler.run(out=...) are then filled by
+    an asynchronous DMA.  Freed when the array (and every view of it) is garbage-collected."""
+    L = lib()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = L.tamcmc_hip_host_alloc(max(n, 1))
+    if not p:
+        raise MemoryError("tamcmc_hip_host_alloc failed")
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, L.tamcmc_hip_host_free, p)
+    return arr
 
 
 def build_mode_table(model_id, params, plength, x):
@@ -234,6 +251,12 @@ class HipContext:
         ms, n, e = C.c_double(0), C.c_int64(0), C.c_int64(0)
         self._chk(self._L.tamcmc_hip_get_kernel_stats(self._h, C.byref(ms), C.byref(n), C.byref(e)))
         return ms.value, n.value, e.value
+
+    def fd_stats(self):
+        """(bins inside the affected ranges, delta evaluations) of the windowed finite-difference launches since the last reset."""
+        b, e = C.c_int64(0), C.c_int64(0)
+        self._chk(self._L.tamcmc_hip_get_fd_stats(self._h, C.byref(b), C.byref(e)))
+        return b.value, e.value
 
     def reset_kernel_stats(self):
         self._chk(self._L.tamcmc_hip_reset_kernel_stats(self._h))

@@ -100,6 +100,15 @@ int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
     }
 }
 
+void *tamcmc_hip_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void tamcmc_hip_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *c, const double *x, const double *y, int64_t Nx) {
     if (!c || !x || !y || Nx < 2 || Nx > 0x7fffffff) return TAMCMC_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -330,11 +339,20 @@ int tamcmc_hip_get_kernel_stats(tamcmc_hip_ctx *c, double *kernel_ms_total, int6
     return TAMCMC_OK;
 }
 
+int tamcmc_hip_get_fd_stats(tamcmc_hip_ctx *c, int64_t *affected_bins, int64_t *delta_evaluations) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    if (affected_bins) *affected_bins = c->fd_bins;
+    if (delta_evaluations) *delta_evaluations = c->fd_delta_evals;
+    return TAMCMC_OK;
+}
+
 int tamcmc_hip_reset_kernel_stats(tamcmc_hip_ctx *c) {
     if (!c) return TAMCMC_ERR_BAD_ARG;
     c->kernel_ms = 0;
     c->launches = 0;
     c->evals = 0;
+    c->fd_bins = 0;
+    c->fd_delta_evals = 0;
     return TAMCMC_OK;
 }
 

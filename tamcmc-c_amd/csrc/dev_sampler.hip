@@ -119,8 +119,12 @@ __device__ void accept_result(const DevSamplerArgs &a, int j, long itp, int P, d
 // Data exchanged between workgroups of ONE launch (the tiles' partial sums, the swap pair's outcomes) goes through device-scope
 // accesses that bypass the per-XCD L2 (MI355X: eight L2s, not coherent with each other for ordinary loads/stores).  A full
 // __threadfence() per tile would write back and invalidate the XCD's whole L2 -- including the resident spectrum -- 4000 times per launch.
-__device__ __forceinline__ double coherent_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coherent_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (global address space spelled out: the accesses must be global_load/global_store ... sc1, not flat_ -- MI355X_MICROARCH.md, cross-workgroup
+// hand-offs: sc1 stores, vmcnt(0), an agent-scope atomic add; the workgroup whose add came last reads with sc1 loads)
+typedef double __attribute__((address_space(1))) *gdp_t;
+typedef const double __attribute__((address_space(1))) *gcdp_t;
+__device__ __forceinline__ double coherent_load(const double *p) { return __hip_atomic_load((gcdp_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(double *p, double v) { __hip_atomic_store((gdp_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every earlier memory operation of this wave has completed (write-through stores have reached memory) before anything later issues
 __device__ __forceinline__ void drain_memory_ops() {
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -1122,13 +1126,19 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         a.bg = c->d_bg.p;
     }
     I.f.bg = (a.bg && use_fused) ? a.bg + C * (size_t)a.ntiles * 8 : nullptr;
+    // record buffers: at least 256 iterations' worth and grown geometrically, so that a caller that records in buffers of a fixed
+    // length (the reference's Nbuffer) or a short call after a shorter one never pays an allocation -- nor, with it, new kernel
+    // arguments -- in its steady state (older, smaller buffers are released with the sampler)
+    auto grown = [](size_t need, size_t have, size_t unit) { const size_t floor_ = 256 * unit; return std::max(std::max(need, floor_), have * 2); };
     if (samples && I.smp_cap < (size_t)n_iter * C * Nv) {
-        DCHK(I.dalloc(&a.samples, (size_t)n_iter * C * Nv));  // (older, smaller buffers are released with the sampler)
-        I.smp_cap = (size_t)n_iter * C * Nv;
+        const size_t cap = grown((size_t)n_iter * C * Nv, I.smp_cap, C * Nv);
+        DCHK(I.dalloc(&a.samples, cap));
+        I.smp_cap = cap;
     }
     if (stats && I.stat_cap < (size_t)n_iter * C * 3) {
-        DCHK(I.dalloc(&a.stats, (size_t)n_iter * C * 3));
-        I.stat_cap = (size_t)n_iter * C * 3;
+        const size_t cap = grown((size_t)n_iter * C * 3, I.stat_cap, C * 3);
+        DCHK(I.dalloc(&a.stats, cap));
+        I.stat_cap = cap;
     }
     DevSamplerArgs args = a;
     if (!samples) args.samples = nullptr;
@@ -1162,6 +1172,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     }
 
     int used_ev = 0;
+    std::vector<std::pair<int, long>> fused_ev;  // (event pair, launches it brackets) of the fused stretches of this call
     int P = I.parity;
     double kernel_ms = 0;
     long n_launch = 0, n_eval = 0;
@@ -1239,7 +1250,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             pending = 1;
             if (i < ib) {
                 for (int g = 0; g < G; g++) {
-                    const bool timed = g == 0 && c->timing && ((i - ia) % ev_every == 0) && used_ev < I.n_ev;
+                    const bool timed = g == 0 && c->timing && ((i - ia) % ev_every == 0) && used_ev < I.n_ev - 16;  // (the top 16 pairs: fused stretches)
                     if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], I.gst[g]));
                     DCHK(launch_loglike(la[g], c->precision, c->wgs, c->K, false, I.gst[g]));
                     if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], I.gst[g])); used_ev++; }
@@ -1292,8 +1303,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         }
         // the likelihood kernel's time for the roofline: two events around the whole stretch (launches back to back on one stream),
         // i.e. the average includes the ~1.4 us between two launches
-        const bool timed = c->timing && used_ev < I.n_ev;
-        if (timed) DCHK(hipEventRecord(I.ev[used_ev][0], st));
+        const bool timed = c->timing && fused_ev.size() < 16;
+        const int fe = I.n_ev - 1 - (int)fused_ev.size();
+        if (timed) DCHK(hipEventRecord(I.ev[fe][0], st));
         for (long i = ia; i < ib; i++) {
             // every launch also prepares the next iteration's candidates and the L z after that -- the last one too (see armed_it)
             sc.it = it0 + i; sc.rec = (samples || stats) ? i : (long)-1; sc.q = q;
@@ -1310,19 +1322,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + grid_tiles, st, args, f, lq, sc));
             q ^= 1;
         }
-        if (timed) { DCHK(hipEventRecord(I.ev[used_ev][1], st)); used_ev++; }
+        if (timed) {  // (read after the call's final synchronisation)
+            DCHK(hipEventRecord(I.ev[fe][1], st));
+            fused_ev.push_back({fe, len});
+        }
         P = q;
         I.armed_it = it0 + ib;
         I.armed_q = q;
-        if (timed) {
-            DCHK(hipStreamSynchronize(st));
-            float ms = 0;
-            DCHK(hipEventElapsedTime(&ms, I.ev[used_ev - 1][0], I.ev[used_ev - 1][1]));
-            used_ev = 0;
-            kernel_ms += ms;
-            n_launch += len;
-            n_eval += len * (long)a.C;
-        }
         return TAMCMC_OK;
     };
 
@@ -1355,6 +1361,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
     DCHK(hipStreamSynchronize(st));
+    for (const auto &e : fused_ev) {
+        float ms = 0;
+        DCHK(hipEventElapsedTime(&ms, I.ev[e.first][0], I.ev[e.first][1]));
+        kernel_ms += ms;
+        n_launch += e.second;
+        n_eval += e.second * (long)a.C;
+    }
     c->kernel_ms += kernel_ms;
     c->launches += n_launch;
     c->evals += n_eval;

@@ -327,6 +327,12 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
         c->kernel_ms += ms;
         c->launches += 1;
         c->evals += B;
+        if (windowed) {  // what the delta launch really touched (roofline bookkeeping of bench.py)
+            std::vector<int> rg((size_t)2 * B);
+            HIPCHK(c, hipMemcpy(rg.data(), db + o_drange, rg.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int s = 0; s < B; s++) c->fd_bins += rg[2 * (size_t)s + 1] - rg[2 * (size_t)s];
+            c->fd_delta_evals += B;
+        }
     }
     const double *lpp = (const double *)(hb + o_lpp), *lpm = (const double *)(hb + o_lpm);
     const int *stt = (const int *)(hb + o_st);

@@ -598,8 +598,9 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     if (tid == 0) {
         double *p = a.partials + ((size_t)b * a.ntiles + tile) * 2;
         if (COH) {
-            __hip_atomic_store(p, out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p + 1, out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            typedef double __attribute__((address_space(1))) *gdp_t;  // global_store ... sc1 (not flat_)
+            __hip_atomic_store((gdp_t)p, out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gdp_t)p + 1, out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             p[0] = out[0];
             p[1] = out[1];

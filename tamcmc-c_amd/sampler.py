@@ -113,10 +113,19 @@ class Sampler:
         except Exception:
             pass
 
-    def run(self, n_iter, record=True, stats=False):
+    def run(self, n_iter, record=True, stats=False, out=None):
+        """Advances the chains by n_iter iterations; returns (samples [n x Nchains x Nvars] or None, stats [n x Nchains x 3] or None).
+        out = (samples, stats): caller-owned C-contiguous float64 arrays of those shapes to fill instead of new ones (a run that
+        writes buffer after buffer, like the reference's Nbuffer ring, reuses them; pinned_empty() arrays avoid the staged copy)."""
         n_iter = int(n_iter)
-        smp = np.zeros((n_iter, self.nchains, self.nvars)) if record else None
-        stt = np.zeros((n_iter, self.nchains, 3)) if stats else None
+        if out is not None:
+            smp, stt = out
+            record, stats = smp is not None, stt is not None
+            assert smp is None or (smp.flags.c_contiguous and smp.dtype == np.float64 and smp.shape == (n_iter, self.nchains, self.nvars))
+            assert stt is None or (stt.flags.c_contiguous and stt.dtype == np.float64 and stt.shape == (n_iter, self.nchains, 3))
+        else:
+            smp = np.zeros((n_iter, self.nchains, self.nvars)) if record else None
+            stt = np.zeros((n_iter, self.nchains, 3)) if stats else None
         st = self._L.tamcmc_sampler_run(self._h, n_iter, _p(smp), _p(stt))
         if st != OK:
             raise TamcmcError(st, self._L.tamcmc_hip_last_error(self.ctx._h).decode())
