@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries under profiles/."""
-import csv, glob, json, os, sys, collections
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+"""Turns gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries under profiles/:
+<tag>_kernel_stats.csv, <tag>_rocprof_summary.md, <tag>_pmc_traffic.json, <tag>_pmc_sq.json."""
+import csv, glob, json, os, shutil, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/prof_{tag}"
+KERNEL = "k_step<1, 8>"          # the dominant kernel of the headline run: fused step, FAST arithmetic, 8 bins per lane
 os.makedirs("profiles", exist_ok=True)
 lines = [f"# rocprofv3 summary {tag} (MI355X, one GPU)", ""]
+
+
 def newest(pattern):
     """gpurun merges new files over old ones (run ids are process ids, not ordered): keep the files of the most recent run."""
     fs = glob.glob(pattern)
@@ -17,12 +21,15 @@ def newest(pattern):
 
 ks = newest(f"{src}/trace/*/*kernel_stats.csv")
 if ks:
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --headline-only` (the default run without its extra legs: only the timed headline launches and their warm-up)", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --headline-only`", "",
+              "(set-up phase = 1500 burn-in + learning iterations, 1000 of them with adaptation -> `k_iterate`/`k_loglike` lockstep launches; "
+              "warm-up 200 + timed 5000 acquire iterations -> one `k_step` launch each)", "",
               "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks[0])):
         lines.append(f"| `{r['Name'][:110]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.2f} | "
                      f"{float(r['Percentage']):.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} |")
     lines.append("")
+    shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
 try:
     b = json.loads(open(f"{src}/bench.json").read())
     lines += ["## `python3 bench.py` line of the same build (un-profiled default run, all legs)", "", "```json", json.dumps(b, indent=1), "```", ""]
@@ -32,28 +39,45 @@ agg = collections.defaultdict(list)
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     for f in newest(f"{src}/{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "k_loglike<1, 64, 8, false" in r["Kernel_Name"]:
+            if KERNEL in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+calib = collections.defaultdict(list)
+for f in newest(f"{src}/calib_fetch/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        calib[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+if calib:
+    lines += ["## FETCH_SIZE calibration (tools/pmc_calib.hip: each launch streams 1 GiB = 1 048 576 KB once)", "", "| kernel | FETCH_SIZE (KB) | bytes read / (FETCH_SIZE x 1024) |", "|---|---|---|"]
+    for k, v in calib.items():
+        m = sum(v) / len(v)
+        lines.append(f"| `{k}` | {m:.0f} | {1048576.0 / m:.3f} |")
+    lines += ["", "FETCH_SIZE counts half the bytes for 8-byte-per-lane coalesced loads (this path's x / y reads) exactly as for 16-byte ones: the x2 "
+              "correction of MI355X_MICROARCH.md applies unchanged.", ""]
 if agg:
-    lines += ["## PMC, kernel `k_loglike<FAST, workgroup 64, K=8>` (default geometry), 10-evaluation launch (C3: one chain group of the device sampler), mean over 10 launches, separate passes", "",
-              "| counter | mean per launch |", "|---|---|"]
-    for k in sorted(agg):
-        lines.append(f"| {k} | {sum(agg[k])/len(agg[k]):.4g} |")
-    fetch = sum(agg["FETCH_SIZE"]) / len(agg["FETCH_SIZE"]) if agg.get("FETCH_SIZE") else None
-    write = sum(agg["WRITE_SIZE"]) / len(agg["WRITE_SIZE"]) if agg.get("WRITE_SIZE") else None
-    if fetch is not None and write is not None:
-        hbm = (2.0 * fetch + write) * 1024.0   # FETCH_SIZE/WRITE_SIZE are in KB; gfx950: FETCH_SIZE reads 1/2 of a wide stream
-        lines += ["", f"HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB = **{hbm/1e6:.2f} MB** "
-                      f"(algorithmic bytes of the launch: 16 B x 1e5 bins x 10 evaluations = 16 MB; the spectrum is served from L2)."]
-        json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write, "correction": "FETCH_SIZE x2 (gfx950)",
-                   "launch": "k_loglike FAST wg=64 K=8, B=10, Nx=1e5", "evaluations": 10}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
-try:
-    old = open(f"profiles/{tag}_rocprof_summary.md").read()
-    keep = old[old.index("## Other legs"):] if "## Other legs" in old else ""
-except Exception:
-    keep = ""
-open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(lines) + "\n" + ("\n" + keep if keep else ""))
-for f in ks:
-    import shutil
-    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
-print("\n".join(lines[:40]))
+    mean = {k: sum(v) / len(v) for k, v in agg.items()}
+    lines += [f"## PMC, kernel `{KERNEL}` (fused step: 20 evaluations x 196 tiles + candidate roles + settle), mean over {len(next(iter(agg.values())))} launches of "
+              "`bench.py --headline-only --steps 300`, separate passes", "", "| counter | mean per launch |", "|---|---|"]
+    for k in sorted(mean):
+        lines.append(f"| {k} | {mean[k]:.4g} |")
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        hbm = (2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0
+        lines += ["", f"HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB = **{hbm/1e6:.2f} MB** against 32 MB algorithmic "
+                      "(16 B x 1e5 bins x 20 evaluations): the spectrum is served from the XCDs' L2s; what reaches the fabric is mostly the "
+                      "candidates' tables and background series (written by the roles, read by the next launch's tiles) and the write-through partial sums."]
+        json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": mean["FETCH_SIZE"], "write_size_kb": mean["WRITE_SIZE"],
+                   "correction": "FETCH_SIZE x2 (gfx950; verified for 8-byte-per-lane loads with tools/pmc_calib.hip in the same session)",
+                   "kernel": KERNEL, "evaluations_per_launch": 20, "algorithmic_bytes_per_launch": 32.0e6,
+                   "source": f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --headline-only "
+                             f"--steps 300, kernel {KERNEL}, FETCH_SIZE x2 (gfx950, calibrated on 8-byte-per-lane reads); not re-measured live"},
+                  open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+    if "SQ_INSTS_VALU" in mean:
+        json.dump({"kernel": KERNEL, "SQ_INSTS_VALU_per_launch": mean["SQ_INSTS_VALU"], "SQ_WAVES_per_launch": mean.get("SQ_WAVES"),
+                   "SQ_ACTIVE_INST_VALU": mean.get("SQ_ACTIVE_INST_VALU"), "SQ_WAVE_CYCLES": mean.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": mean.get("SQ_WAIT_ANY"),
+                   "SQ_WAIT_INST_ANY": mean.get("SQ_WAIT_INST_ANY"), "SQ_BUSY_CYCLES": mean.get("SQ_BUSY_CYCLES")},
+                  open(f"profiles/{tag}_pmc_sq.json", "w"), indent=1)
+        if mean.get("SQ_WAVE_CYCLES"):
+            wc = mean["SQ_WAVE_CYCLES"]
+            lines += ["", f"Wave-cycle split: VALU issuing {100*mean.get('SQ_ACTIVE_INST_VALU',0)/wc:.0f} %, waiting on memory/LDS/barrier (SQ_WAIT_ANY) "
+                          f"{100*mean.get('SQ_WAIT_ANY',0)/wc:.0f} %, issue stalls (SQ_WAIT_INST_ANY) {100*mean.get('SQ_WAIT_INST_ANY',0)/wc:.0f} %; "
+                          f"{mean['SQ_INSTS_VALU']/mean['SQ_WAVES']:.0f} VALU instructions per wave, {mean['SQ_WAVES']:.0f} waves per launch."]
+open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:30]))
