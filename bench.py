@@ -65,6 +65,7 @@ def parse():
                          "rocprofv3 for profiles/, so that the per-kernel averages are those of the headline launches")
     ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
     ap.add_argument("--step-scheme", type=int, default=0, choices=[0, 1], help="device engine: 0 = fused one-launch iterations, 1 = lockstep kernels only")
+    ap.add_argument("--dump-samples", default="", help="every rank saves the samples of its timed region to <this>_rank<r>.npy (multi-rank rehearsal test)")
     a = ap.parse_args()
     a.steps = max(a.steps, 1)
     a.warmup = max(a.warmup, 0)
@@ -190,6 +191,8 @@ def main():
     # ---- end-to-end check of what the timed region left behind: the chains' tempered logL recomputed with STRICT arithmetic from the
     # final positions (the recorded last sample), and the recorded statistics against the state
     samples, stats = rec
+    if a.dump_samples:
+        np.save(f"{a.dump_samples}_rank{rank}.npy", np.array(samples))
     Pfin = np.tile(star.params, (a.chains, 1))
     Pfin[:, star.index_to_relax] = st["vars"]
     ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_STRICT)
