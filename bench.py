@@ -171,8 +171,8 @@ def main():
     use_drift = 1 if a.sampler == "mala" else 0
     smp = make_sampler(use_drift, a.engine)
     # ---- set-up phase (untimed): burn-in + learning; its last stretch already runs the acquire-phase launch pattern
-    smp.run(SETUP_ITERS if not use_drift else 150, record=False)
-    mark(f"sampler set-up: burn-in + learning phase ({SETUP_ITERS if not use_drift else 150} iterations, adaptation in {SETUP_LEARN})")
+    smp.run(SETUP_ITERS if not use_drift else 300, record=False)
+    mark(f"sampler set-up: burn-in + learning phase ({SETUP_ITERS if not use_drift else 300} iterations, adaptation from iteration {SETUP_LEARN[0]} on)")
     # record buffers the run() calls fill: the samples and the statistics of every iteration (page-locked, like a writer's ring buffer)
     nrec = max(a.steps, a.warmup, 1)
     buf_smp, buf_st = pkg.pinned_empty((nrec, a.chains, smp.nvars)), pkg.pinned_empty((nrec, a.chains, 3))
@@ -206,8 +206,8 @@ def main():
 
     extra = {}
     if a.mala_steps > 0 and a.sampler == "mh" and world == 1:
-        ms = make_sampler(1, "host")
-        ms.run(150, record=False)   # adaptation in [100, 150): the Langevin proposal needs its step size tuned
+        ms = make_sampler(1, a.engine)
+        ms.run(300, record=False)   # adaptation in [100, 300): the Langevin proposal needs its step size tuned
         ctx.reset_kernel_stats()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -221,7 +221,8 @@ def main():
         mala_bytes = 24.0 * a.nx * a.chains * mk_l + 24.0 * fd_bins
         macc = np.mean(np.any(msmp[1:] != msmp[:-1], axis=2), axis=0) if a.mala_steps > 1 else np.zeros(a.chains)
         extra["mala_fd"] = {"samples_per_s": a.mala_steps / e1, "steps": a.mala_steps, "evals_per_step": mk_e / a.mala_steps,
-                            "engine": "host-driven loop + device finite-difference batches (windowed delta tables)",
+                            "engine": ("device-resident Langevin step (k_mala_settle -> finite-difference batch -> k_mala_test, nothing crosses PCIe)"
+                                       if a.engine == "device" else "host-driven loop + device finite-difference batches") + ", windowed delta tables",
                             "accept_rate_chain0": float(macc[0]), "accept_rate_mean": float(macc.mean()),
                             "roofline": {"bound": "hbm", "kernel": "base k_loglike (model rows kept) + k_loglike<DELTA> per FD batch",
                                          "kernel_us_per_batch": mk_ms / max(mk_l, 1) * 1e3,

@@ -32,6 +32,7 @@ struct DevSamplerArgs {
     // proposal law
     double *LT, *cov, *mu, *sigma;   // LT = transposed Cholesky factor of (cov+eps2)*sigma
     double *lz;           // [2][C][Nv] L z of the NEXT iteration, computed ahead by spare workgroups while L is frozen
+    double *grad_cur, *gradP_cur;  // Langevin step: [2][C][Nv] gradient of the tempered log-posterior at the chains' positions, and the prior's share
     // likelihood-kernel input block written by k_propose_unpack
     tamcmc_multiplet *mults;
     int *pairs, *nh, *nn;
@@ -54,6 +55,8 @@ struct DevSamplerInit {
     double c0, epsilon1, epsi2, A1, target_acceptance;
     int chain_groups = 0;  // 0 = default (2 from 8 chains on): stream groups of the lockstep scheme
     int swap_rule = 0;     // tamcmc_sampler_config.swap_rule
+    int use_drift = 0;     // 1: Langevin step (dev_mala_impl.h)
+    double delta = 0, fd_step_rel = 1e-7;  // drift truncation (0 = none), relative forward-difference step
 };
 
 class DevSampler {
@@ -73,6 +76,7 @@ class DevSampler {
                        int *moved, long *counters);
     int download_proposal(int m, double *cov, double *mu, double *sigma);
     int run(long it0, long n_iter, const char *learn, double *samples, double *stats);
+    int run_mala(long it0, long n_iter, const char *learn, double *samples, double *stats);  // use_drift = 1 (dev_mala_impl.h)
 };
 
 }  // namespace tamcmc

@@ -38,6 +38,7 @@
 #include "kernels.h"
 #include "loglike_tile.h"
 #include "dev_unpack.h"
+#include "fd_batch.h"
 #include "mode_tables.h"
 #include "rng.h"
 
@@ -821,6 +822,8 @@ hipError_t launch_step(int mode, int K, int grid, hipStream_t st, const DevSampl
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 
+#include "dev_mala_impl.h"
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -842,6 +845,17 @@ struct DevSampler::Impl {
     FusedArgs f{};       // (A): candidate slots, tickets
     unsigned char *d_argcopy = nullptr;  // device image of {DevSamplerArgs, FusedArgs} as last launched, and its host shadow
     std::vector<unsigned char> h_argcopy;
+    // Langevin step (use_drift): the finite-difference batch object, its device block and scratch, the per-chain work arrays
+    bool use_drift = false;
+    double delta = 0, fd_step_rel = 1e-7;
+    FdBatch fd;
+    DevBuf<unsigned char> fd_block;
+    DevBuf<double> fd_part, fd_S, fd_model, fd_bg;
+    MalaArgs mala{};
+    bool grad_valid = false;
+    int prior_class = 0, model_id = 0;
+    std::vector<double> h_priors, h_extra;
+    std::vector<int32_t> h_idx, h_sw;
     // (A) carried over between run() calls: the last launch of a fused stretch also prepares the candidates of the iteration that
     // follows and the L z of the one after; a call that continues right there starts without the two entry launches
     long armed_it = -1;
@@ -874,6 +888,7 @@ DevSampler::~DevSampler() {
         (void)hipStreamSynchronize(impl->ctx->stream);
     }
     for (void *p : impl->allocs) (void)hipFree(p);
+    impl->fd_block.release(); impl->fd_part.release(); impl->fd_S.release(); impl->fd_model.release(); impl->fd_bg.release();
     if (impl->h_pack) (void)hipHostFree(impl->h_pack);
     for (int i = 0; i < impl->n_ev; i++) { (void)hipEventDestroy(impl->ev[i][0]); (void)hipEventDestroy(impl->ev[i][1]); }
     if (impl->ev_made) {
@@ -908,6 +923,10 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     a.desc.model_id = in.model_id; a.desc.prior_class = in.prior_class; a.C = in.C; a.desc.Np = in.Np; a.Nv = in.Nv;
     a.desc.per = mt::count_multiplets(in.model_id, in.plength);
     I.h_plength.assign(in.plength, in.plength + 11);
+    I.use_drift = in.use_drift != 0; I.delta = in.delta; I.fd_step_rel = in.fd_step_rel > 0 ? in.fd_step_rel : 1e-7;
+    I.prior_class = in.prior_class; I.model_id = in.model_id;
+    I.h_priors.assign(in.priors, in.priors + 4 * (size_t)in.Np); I.h_extra.assign(in.extra_priors, in.extra_priors + 10);
+    I.h_idx.assign(in.index_to_relax, in.index_to_relax + in.Nv); I.h_sw.assign(in.priors_switch, in.priors_switch + in.Np);
     if (a.desc.per < 0) return TAMCMC_ERR_BAD_MODEL;
     a.desc.stride = in.plength[8] > 0 ? in.plength[8] : 1;
     if ((a.desc.stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
@@ -932,6 +951,12 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.logL_cur, 2 * C)); DCHK(I.dalloc(&a.logPr_cur, 2 * C)); DCHK(I.dalloc(&a.logPost_cur, 2 * C));
     DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * CD)); DCHK(I.dalloc(&a.status_prop, 2 * CD));
     DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8));
+    a.grad_cur = nullptr; a.gradP_cur = nullptr;
+    if (I.use_drift) {
+        DCHK(I.dalloc(&a.grad_cur, 2 * C * Nv)); DCHK(I.dalloc(&a.gradP_cur, 2 * C * Nv));
+        DCHK(I.dalloc(&I.mala.grad_prop, C * Nv)); DCHK(I.dalloc(&I.mala.gradP_prop, C * Nv)); DCHK(I.dalloc(&I.mala.drift_cur, C * Nv));
+        DCHK(I.dalloc(&I.mala.out, C * 5));
+    }
     DCHK(I.dalloc(&a.lz, 2 * C * Nv)); DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, CD * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * CD)); DCHK(I.dalloc(&a.nh, CD)); DCHK(I.dalloc(&a.nn, CD));
     DCHK(I.dalloc(&a.noise, CD * (size_t)a.desc.stride));
@@ -996,6 +1021,7 @@ int DevSampler::upload_state(const double *vars, const double *params, const dou
                              const double *logPost, const double *init_logL) {
     Impl &I = *impl;
     I.armed_it = -1;
+    I.grad_valid = false;
     tamcmc_hip_ctx *c = I.ctx;
     DevSamplerArgs &a = I.a;
     const size_t C = (size_t)a.C, Np = (size_t)a.desc.Np, Nv = (size_t)a.Nv;
@@ -1110,6 +1136,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     tamcmc_hip_ctx *c = I.ctx;
     DevSamplerArgs &a = I.a;
     if (n_iter <= 0) return TAMCMC_OK;
+    if (I.use_drift) return run_mala(it0, n_iter, learn, samples, stats);
     DCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t C = (size_t)a.C, Nv = (size_t)a.Nv;
@@ -1371,6 +1398,122 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     c->kernel_ms += kernel_ms;
     c->launches += n_launch;
     c->evals += n_eval;
+    return TAMCMC_OK;
+}
+
+// The Langevin engine (use_drift): per iteration k_mala_settle (settle it-1, propose it) -> the finite-difference batch of the proposals
+// (k_fd_unpack, base k_loglike with model rows, k_loglike<DELTA>, k_finalize x2) -> k_mala_test.  See dev_mala_impl.h.
+int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *samples, double *stats) {
+    Impl &I = *impl;
+    tamcmc_hip_ctx *c = I.ctx;
+    DevSamplerArgs &a = I.a;
+    DCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    I.armed_it = -1;
+    const size_t C = (size_t)a.C, Nv = (size_t)a.Nv, Np = (size_t)a.desc.Np;
+    {   // the batch's layout follows the context's options (arithmetic mode, geometry, windowed differences): re-laid out when they change
+        FdBatch nb;
+        int rc = nb.layout(c, I.model_id, I.prior_class, a.C, (int64_t)Np, I.h_plength.data(), a.Nv);
+        if (rc) return rc;
+        if (nb.total_bytes != I.fd.total_bytes || nb.windowed != I.fd.windowed || nb.ntiles != I.fd.ntiles || !I.fd_block.p) {
+            I.fd = nb;
+            rc = fd_ensure_poly(c);
+            if (rc) return rc;
+            DCHK(I.fd_block.reserve(nb.total_bytes));
+            std::vector<unsigned char> hb(nb.in_bytes, 0);
+            std::memcpy(hb.data() + nb.o_pr, I.h_priors.data(), 4 * Np * 8);
+            std::memcpy(hb.data() + nb.o_ex, I.h_extra.data(), 10 * 8);
+            std::memcpy(hb.data() + nb.o_sw, I.h_sw.data(), Np * 4);
+            std::memcpy(hb.data() + nb.o_pl, I.h_plength.data(), 11 * 4);
+            std::memcpy(hb.data() + nb.o_idx, I.h_idx.data(), Nv * 4);
+            DCHK(hipMemcpyAsync(I.fd_block.p, hb.data(), nb.in_bytes, hipMemcpyHostToDevice, st));
+            DCHK(hipStreamSynchronize(st));
+            DCHK(I.fd_part.reserve(nb.nS * (size_t)nb.ntiles * 2));
+            DCHK(I.fd_S.reserve(nb.nS));
+            if (nb.windowed) DCHK(I.fd_model.reserve(C * (size_t)c->Nx));
+            if (c->precision == TAMCMC_PRECISION_FAST) DCHK(I.fd_bg.reserve((size_t)(nb.windowed ? a.C : nb.B) * nb.ntiles * 8));
+            I.grad_valid = false;
+        }
+    }
+    FdBatch &fd = I.fd;
+    unsigned char *db = I.fd_block.p;
+    MalaArgs M = I.mala;
+    M.S = I.fd_S.p; M.lpp = (const double *)(db + fd.o_lpp); M.lpm = (const double *)(db + fd.o_lpm); M.st = (const int *)(db + fd.o_st);
+    M.h = (double *)(db + fd.o_h); M.E = fd.E; M.windowed = fd.windowed ? 1 : 0; M.fd_step_rel = I.fd_step_rel; M.delta = I.delta;
+    if (samples && I.smp_cap < (size_t)n_iter * C * Nv) {
+        DCHK(I.dalloc(&a.samples, (size_t)n_iter * C * Nv));
+        I.smp_cap = (size_t)n_iter * C * Nv;
+    }
+    if (stats && I.stat_cap < (size_t)n_iter * C * 3) {
+        DCHK(I.dalloc(&a.stats, (size_t)n_iter * C * 3));
+        I.stat_cap = (size_t)n_iter * C * 3;
+    }
+    DevSamplerArgs args = a;
+    if (!samples) args.samples = nullptr;
+    if (!stats) args.stats = nullptr;
+    const size_t lds_settle = (4 * Nv + Np + 1 + 8) * sizeof(double) + 32;
+    const size_t lds_test0 = (5 * Nv + 8) * sizeof(double) + 32, lds_adapt = (Nv * Nv + Nv) * sizeof(double);
+    const bool chol_lds = lds_test0 + lds_adapt <= 156 * 1024;
+    args.chol_in_lds = chol_lds ? 1 : 0;
+    if (!chol_lds && !I.adapt_scratch) DCHK(I.dalloc(&I.adapt_scratch, C * (Nv * Nv + Nv)));
+    if (lds_test0 + lds_adapt > 64 * 1024 && chol_lds)
+        DCHK(hipFuncSetAttribute((const void *)k_mala_test, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_test0 + lds_adapt)));
+    int P = I.parity;
+    auto batch = [&](const double *d_params, bool timed) -> int {
+        return fd.enqueue(c, db, d_params, I.fd_part.p, I.fd_S.p, I.fd_model.p, I.fd_bg.p, timed ? I.ev[0][0] : nullptr, timed ? I.ev[0][1] : nullptr);
+    };
+    if (!I.grad_valid) {  // gradient at the chains' current positions (start of a run, new positions from outside)
+        hipLaunchKernelGGL(k_mala_steps, dim3(1), dim3(256), 0, st, args, M);
+        int rc = batch(a.params_cur + (size_t)P * C * Np, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_mala_ginit, dim3(a.C), dim3(TB), 2 * Nv * sizeof(double), st, args, M, P);
+        DCHK(hipGetLastError());
+        I.grad_valid = true;
+    }
+    double kernel_ms = 0;
+    long n_timed = 0, fd_bins_sampled = 0;
+    int pending = 0;
+    for (long i = 0; i <= n_iter; i++) {
+        const long it = it0 + i;
+        const long rec = (pending && (samples || stats)) ? i - 1 : (long)-1;
+        if (i < n_iter) hipLaunchKernelGGL(k_mala_settle<true>, dim3(a.C), dim3(TB), lds_settle, st, args, M, it, P, pending, rec);
+        else hipLaunchKernelGGL(k_mala_settle<false>, dim3(a.C), dim3(TB), lds_settle, st, args, M, it, P, pending, rec);
+        P ^= 1;
+        pending = 1;
+        if (i == n_iter) break;
+        const bool timed = c->timing && (i == 0 || i == n_iter / 2);  // two sampled batches per call (an event read needs a synchronisation)
+        int rc = batch(a.params_prop, timed);
+        if (rc) return rc;
+        const int learn_i = (learn && learn[i]) ? 1 : 0;
+        hipLaunchKernelGGL(k_mala_test, dim3(a.C), dim3(TB), lds_test0 + ((learn_i && chol_lds) ? lds_adapt : 0), st, args, M, it, P, learn_i,
+                           I.adapt_scratch);
+        if (timed) {
+            DCHK(hipStreamSynchronize(st));
+            float ms = 0;
+            DCHK(hipEventElapsedTime(&ms, I.ev[0][0], I.ev[0][1]));
+            kernel_ms += ms;
+            n_timed++;
+            if (fd.windowed) {  // what the delta launch really touched (roofline bookkeeping, as fd_run does)
+                std::vector<int> rg((size_t)2 * fd.B);
+                DCHK(hipMemcpy(rg.data(), db + fd.o_drange, rg.size() * sizeof(int), hipMemcpyDeviceToHost));
+                long bins = 0;
+                for (int q2 = 0; q2 < fd.B; q2++) bins += rg[2 * (size_t)q2 + 1] - rg[2 * (size_t)q2];
+                fd_bins_sampled += bins;
+            }
+        }
+    }
+    I.parity = P;
+    DCHK(hipGetLastError());
+    if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
+    if (stats) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
+    DCHK(hipStreamSynchronize(st));
+    if (n_timed) {  // (the sampled batches stand for all of them)
+        c->kernel_ms += kernel_ms / n_timed * n_iter;
+        c->launches += n_iter;
+        c->evals += n_iter * (long)fd.B;
+        c->fd_bins += fd_bins_sampled / n_timed * n_iter;
+        c->fd_delta_evals += fd.windowed ? n_iter * (long)fd.B : 0;
+    }
     return TAMCMC_OK;
 }
 

@@ -15,6 +15,7 @@
 #include "ctx.h"
 #include "dev_unpack.h"
 #include "kernels.h"
+#include "fd_batch.h"
 
 namespace tamcmc {
 namespace {
@@ -168,6 +169,149 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
 
 using namespace tamcmc;
 
+// ---------------------------------------------------------------------------------------------------------------
+// One finite-difference batch = C chains x (Nvars + 1) evaluations.  fd_layout() places its constants, tables and results in ONE
+// device block; fd_enqueue() launches the batch on the context's stream from parameter vectors that are ALREADY on the device and
+// leaves the results there (the device-resident Langevin step, dev_mala.hip, consumes them in its next kernel); fd_run() is the host
+// entry: upload, enqueue, download, gradient assembly.
+namespace tamcmc {
+
+static size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+int FdBatch::layout(tamcmc_hip_ctx *c, int model_id_, int prior_class_, int C_, int64_t Nparams, const int32_t *plength, int Nvars_) {
+    model_id = model_id_; prior_class = prior_class_; C = C_; Np = Nparams; Nvars = Nvars_;
+    per = mt::count_multiplets(model_id, plength);
+    if (per < 0) return TAMCMC_ERR_BAD_MODEL;
+    stride = plength[8] > 0 ? plength[8] : 1;
+    if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
+    E = Nvars + 1; B = C * E;
+    const size_t Nv = (size_t)Nvars;
+    size_t o = 0;
+    o_params = o; o = al16(o + (size_t)C * Np * 8);
+    o_h = o; o = al16(o + Nv * 8);
+    o_pr = o; o = al16(o + 4 * (size_t)Np * 8);
+    o_ex = o; o = al16(o + 10 * 8);
+    o_pl = o; o = al16(o + 11 * 4);
+    o_idx = o; o = al16(o + Nv * 4);
+    o_sw = o; o = al16(o + (size_t)Np * 4);
+    in_bytes = o;
+    o_lpp = o; o = al16(o + (size_t)B * 8);
+    o_lpm = o; o = al16(o + (size_t)B * 8);
+    o_st = o; o = al16(o + (size_t)B * 4);
+    out_bytes = o - in_bytes;
+    // windowed finite differences (FAST modes): only the multiplets a perturbation changes are re-evaluated, on their
+    // windows, against the stored base model row (SURVEY section 7, step 6: "the main algorithmic lever")
+    windowed = c->fd_windowed && c->precision != TAMCMC_PRECISION_STRICT && delta_geometry(c->wgs, c->K) && Nvars > 0;
+    const int nslots = windowed ? 2 * B : B;                   // windowed: slots [B, 2B) = per-block copies of the base table
+    const StageLayout L(nslots, stride, (size_t)nslots * per);
+    o_tab = o; o = al16(o + L.bytes);
+    o_dtab = o_btab = o_drange = o_dflags = o_drow = o_dnold = 0;
+    if (windowed) {
+        const StageLayout LD(B, stride, (size_t)B * 2 * per);      // delta launch input block
+        const StageLayout LB(C, stride, 0);                        // base launch: ranges / counts / noise rows by chain
+        o_dtab = o; o = al16(o + LD.bytes);
+        o_btab = o; o = al16(o + LB.bytes);
+        o_drange = o; o = al16(o + (size_t)2 * B * 4);
+        o_dflags = o; o = al16(o + (size_t)B * 4);
+        o_drow = o; o = al16(o + (size_t)B * 4);
+        o_dnold = o; o = al16(o + (size_t)B * stride * 8);
+    }
+    total_bytes = o;
+    const int tbins = tile_bins(c->wgs, c->K);
+    ntiles = (int)((c->Nx + tbins - 1) / tbins);
+    nS = windowed ? (size_t)C + B : (size_t)B;
+    return TAMCMC_OK;
+}
+
+// db = the batch's device block (total_bytes), constants in place; d_params: C x Np parameter vectors on the device (nullptr: the
+// block's own params area); part / S / model: scratch sized nS*ntiles*2, nS, C*Nx (model only when windowed); bgbuf: C or B x ntiles x 8.
+int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_params, double *part, double *S, double *model, double *bgbuf,
+                     hipEvent_t ev0, hipEvent_t ev1) {
+    hipStream_t st = c->stream;
+    auto table_ptrs = [](unsigned char *base, const StageLayout &Lx) {
+        TablePtrs T;
+        T.mults = (tamcmc_multiplet *)(base + Lx.off_mults); T.pairs = (int *)(base + Lx.off_pairs);
+        T.nh = (int *)(base + Lx.off_nh); T.nn = (int *)(base + Lx.off_nn); T.noise = (double *)(base + Lx.off_noise);
+        return T;
+    };
+    const int nslots = windowed ? 2 * B : B;
+    const StageLayout L(nslots, stride, (size_t)nslots * per), LD(B, stride, (size_t)B * 2 * per), LB(C, stride, 0);
+    FdArgs fa;
+    fa.desc.model_id = model_id; fa.desc.prior_class = prior_class; fa.desc.Np = (int)Np; fa.desc.per = per;
+    fa.desc.stride = stride; fa.desc.Nx = (int)c->Nx;
+    fa.desc.x_first = c->hx[0]; fa.desc.x_last = c->hx[(size_t)c->Nx - 1]; fa.desc.step = c->hx[1] - c->hx[0];
+    fa.desc.plength = (const int *)(db + o_pl); fa.desc.priors_switch = (const int *)(db + o_sw);
+    fa.desc.priors = (const double *)(db + o_pr); fa.desc.extra = (const double *)(db + o_ex); fa.desc.poly = c->d_poly.p;
+    fa.T = table_ptrs(db + o_tab, L);
+    fa.C = C; fa.E = E; fa.Nv = Nvars;
+    fa.params = d_params ? d_params : (const double *)(db + o_params);
+    fa.idx = (const int *)(db + o_idx); fa.h = (const double *)(db + o_h);
+    fa.logPr_plus = (double *)(db + o_lpp); fa.logPr_minus = (double *)(db + o_lpm); fa.status = (int *)(db + o_st);
+    fa.windowed = windowed ? 1 : 0;
+    fa.D = fa.T; fa.Bs = fa.T;
+    fa.d_range = nullptr; fa.d_flags = nullptr; fa.d_row = nullptr; fa.d_noise_old = nullptr;
+    if (windowed) {
+        fa.D = table_ptrs(db + o_dtab, LD);
+        fa.Bs = table_ptrs(db + o_btab, LB);
+        fa.d_range = (int *)(db + o_drange); fa.d_flags = (int *)(db + o_dflags); fa.d_row = (int *)(db + o_drow);
+        fa.d_noise_old = (double *)(db + o_dnold);
+    }
+    const size_t lds = (size_t)Np * 8 + unpack_lds_bytes() + 32;
+    hipLaunchKernelGGL(k_fd_unpack, dim3(B), dim3(FB), lds, st, fa);
+    HIPCHK(c, hipGetLastError());
+
+    const int Nx = (int)c->Nx;
+    LoglikeArgs a;
+    a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.ntiles = ntiles;
+    a.x0 = c->hx[0]; a.step = c->hx[1] - c->hx[0];
+    a.noise_stride = stride; a.model = nullptr;
+    if (ev0) HIPCHK(c, hipEventRecord(ev0, st));
+    if (!windowed) {
+        a.B = B;
+        a.mults = fa.T.mults; a.offsets = fa.T.pairs; a.noise = fa.T.noise; a.nharvey = fa.T.nh; a.nnoise = fa.T.nn;
+        a.partials = part;
+        if (c->precision == TAMCMC_PRECISION_FAST) {
+            HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, bgbuf, st));
+            a.bg_poly = bgbuf;
+        }
+        HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, false, st));
+        HIPCHK(c, launch_finalize(part, B, ntiles, S, st));
+    } else {
+        // (1) the C base points: full evaluation, model rows kept
+        a.B = C;
+        a.mults = fa.T.mults; a.offsets = fa.Bs.pairs; a.noise = fa.Bs.noise; a.nharvey = fa.Bs.nh; a.nnoise = fa.Bs.nn;
+        a.partials = part; a.model = model;
+        if (c->precision == TAMCMC_PRECISION_FAST) {
+            HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, bgbuf, st));
+            a.bg_poly = bgbuf;
+        }
+        HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, true, st));
+        HIPCHK(c, launch_finalize(part, C, ntiles, S, st));
+        // (2) the C*Nvars perturbed points: log-likelihood DIFFERENCES from the delta tables
+        LoglikeArgs d = a;
+        d.B = B; d.model = nullptr; d.bg_poly = nullptr;
+        d.mults = fa.D.mults; d.offsets = fa.D.pairs; d.noise = fa.D.noise; d.nharvey = fa.D.nh; d.nnoise = fa.D.nn;
+        d.partials = part + (size_t)C * ntiles * 2;
+        d.d_range = fa.d_range; d.d_flags = fa.d_flags; d.d_row = fa.d_row; d.d_noise_old = fa.d_noise_old; d.model0 = model;
+        HIPCHK(c, launch_loglike_delta(d, c->precision, c->wgs, c->K, st));
+        HIPCHK(c, launch_finalize(d.partials, B, ntiles, S + C, st));
+    }
+    if (ev1) HIPCHK(c, hipEventRecord(ev1, st));
+    return TAMCMC_OK;
+}
+
+int fd_ensure_poly(tamcmc_hip_ctx *c) {
+    if (!c->poly_ready) {
+        HIPCHK(c, c->d_poly.reserve(sizeof(mt::PolyTab)));
+        hipLaunchKernelGGL(k_fill_poly_fd, dim3(1), dim3(64), 0, c->stream, (mt::PolyTab *)c->d_poly.p);
+        HIPCHK(c, hipGetLastError());
+        c->poly_ready = true;
+    }
+    return TAMCMC_OK;
+}
+
+}  // namespace tamcmc
+
 static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const double *params, int64_t Nparams,
                   const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep, const double *Tcoefs,
                   double p, const double *priors, const int32_t *priors_switch, const double *extra_priors, double *logL0,
@@ -182,142 +326,38 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     if (psum != Nparams) return TAMCMC_ERR_BAD_ARG;
     for (int k = 0; k < Nvars; k++)
         if (index_to_relax[k] < 0 || index_to_relax[k] >= Nparams) return TAMCMC_ERR_BAD_ARG;
-    const int per = mt::count_multiplets(model_id, plength);
-    if (per < 0) return TAMCMC_ERR_BAD_MODEL;
-    const int stride = plength[8] > 0 ? plength[8] : 1;
-    if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const int E = Nvars + 1, B = C * E;
+    FdBatch fb;
+    int rc = fb.layout(c, model_id, prior_class, C, Nparams, plength, Nvars);
+    if (rc) return rc;
+    rc = fd_ensure_poly(c);
+    if (rc) return rc;
+    const int E = fb.E, B = fb.B;
     const size_t Np = (size_t)Nparams, Nv = (size_t)Nvars;
-    if (!c->poly_ready) {
-        HIPCHK(c, c->d_poly.reserve(sizeof(mt::PolyTab)));
-        hipLaunchKernelGGL(k_fill_poly_fd, dim3(1), dim3(64), 0, st, (mt::PolyTab *)c->d_poly.p);
-        HIPCHK(c, hipGetLastError());
-        c->poly_ready = true;
-    }
-    // ---- one pinned input block -> one H2D copy ----
-    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    size_t o = 0;
-    const size_t o_params = o; o = al(o + (size_t)C * Np * 8);
-    const size_t o_h = o; o = al(o + Nv * 8);
-    const size_t o_pr = o; o = al(o + 4 * Np * 8);
-    const size_t o_ex = o; o = al(o + 10 * 8);
-    const size_t o_pl = o; o = al(o + 11 * 4);
-    const size_t o_idx = o; o = al(o + Nv * 4);
-    const size_t o_sw = o; o = al(o + Np * 4);
-    const size_t in_bytes = o;
-    // device-only areas
-    const size_t o_lpp = o; o = al(o + (size_t)B * 8);
-    const size_t o_lpm = o; o = al(o + (size_t)B * 8);
-    const size_t o_st = o; o = al(o + (size_t)B * 4);
-    const size_t out_bytes = o - in_bytes;
-    // windowed finite differences (FAST modes): only the multiplets a perturbation changes are re-evaluated, on their
-    // windows, against the stored base model row (SURVEY section 7, step 6: "the main algorithmic lever")
-    const bool windowed = c->fd_windowed && c->precision != TAMCMC_PRECISION_STRICT && delta_geometry(c->wgs, c->K) && Nvars > 0;
-    const int nslots = windowed ? 2 * B : B;                   // windowed: slots [B, 2B) = per-block copies of the base table
-    const StageLayout L(nslots, stride, (size_t)nslots * per);
-    const size_t o_tab = o; o = al(o + L.bytes);
-    const StageLayout LD(B, stride, (size_t)B * 2 * per);      // delta launch input block
-    const StageLayout LB(C, stride, 0);                        // base launch: ranges / counts / noise rows by chain
-    size_t o_dtab = 0, o_btab = 0, o_drange = 0, o_dflags = 0, o_drow = 0, o_dnold = 0;
-    if (windowed) {
-        o_dtab = o; o = al(o + LD.bytes);
-        o_btab = o; o = al(o + LB.bytes);
-        o_drange = o; o = al(o + (size_t)2 * B * 4);
-        o_dflags = o; o = al(o + (size_t)B * 4);
-        o_drow = o; o = al(o + (size_t)B * 4);
-        o_dnold = o; o = al(o + (size_t)B * stride * 8);
-    }
+    const bool windowed = fb.windowed;
+    const size_t in_bytes = fb.in_bytes, out_bytes = fb.out_bytes, o_lpp = fb.o_lpp, o_lpm = fb.o_lpm, o_st = fb.o_st, o_drange = fb.o_drange;
     HIPCHK(c, c->h_fd.reserve(in_bytes + out_bytes));
-    HIPCHK(c, c->d_fd.reserve(o));
+    HIPCHK(c, c->d_fd.reserve(fb.total_bytes));
     unsigned char *hb = c->h_fd.p, *db = c->d_fd.p;
-    std::memcpy(hb + o_params, params, (size_t)C * Np * 8);
-    std::memcpy(hb + o_h, hstep, Nv * 8);
+    std::memcpy(hb + fb.o_params, params, (size_t)C * Np * 8);
+    std::memcpy(hb + fb.o_h, hstep, Nv * 8);
     if (prior_class != 0) {
-        std::memcpy(hb + o_pr, priors, 4 * Np * 8);
-        std::memcpy(hb + o_ex, extra_priors, 10 * 8);
-        std::memcpy(hb + o_sw, priors_switch, Np * 4);
+        std::memcpy(hb + fb.o_pr, priors, 4 * Np * 8);
+        std::memcpy(hb + fb.o_ex, extra_priors, 10 * 8);
+        std::memcpy(hb + fb.o_sw, priors_switch, Np * 4);
     }
-    std::memcpy(hb + o_pl, plength, 11 * 4);
-    std::memcpy(hb + o_idx, index_to_relax, Nv * 4);
+    std::memcpy(hb + fb.o_pl, plength, 11 * 4);
+    std::memcpy(hb + fb.o_idx, index_to_relax, Nv * 4);
     HIPCHK(c, hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
-
-    auto table_ptrs = [](unsigned char *base, const StageLayout &Lx) {
-        TablePtrs T;
-        T.mults = (tamcmc_multiplet *)(base + Lx.off_mults); T.pairs = (int *)(base + Lx.off_pairs);
-        T.nh = (int *)(base + Lx.off_nh); T.nn = (int *)(base + Lx.off_nn); T.noise = (double *)(base + Lx.off_noise);
-        return T;
-    };
-    FdArgs fa;
-    fa.desc.model_id = model_id; fa.desc.prior_class = prior_class; fa.desc.Np = (int)Nparams; fa.desc.per = per;
-    fa.desc.stride = stride; fa.desc.Nx = (int)c->Nx;
-    fa.desc.x_first = c->hx[0]; fa.desc.x_last = c->hx[(size_t)c->Nx - 1]; fa.desc.step = c->hx[1] - c->hx[0];
-    fa.desc.plength = (const int *)(db + o_pl); fa.desc.priors_switch = (const int *)(db + o_sw);
-    fa.desc.priors = (const double *)(db + o_pr); fa.desc.extra = (const double *)(db + o_ex); fa.desc.poly = c->d_poly.p;
-    fa.T = table_ptrs(db + o_tab, L);
-    fa.C = C; fa.E = E; fa.Nv = Nvars;
-    fa.params = (const double *)(db + o_params); fa.idx = (const int *)(db + o_idx); fa.h = (const double *)(db + o_h);
-    fa.logPr_plus = (double *)(db + o_lpp); fa.logPr_minus = (double *)(db + o_lpm); fa.status = (int *)(db + o_st);
-    fa.windowed = windowed ? 1 : 0;
-    fa.D = fa.T; fa.Bs = fa.T;
-    fa.d_range = nullptr; fa.d_flags = nullptr; fa.d_row = nullptr; fa.d_noise_old = nullptr;
-    if (windowed) {
-        fa.D = table_ptrs(db + o_dtab, LD);
-        fa.Bs = table_ptrs(db + o_btab, LB);
-        fa.d_range = (int *)(db + o_drange); fa.d_flags = (int *)(db + o_dflags); fa.d_row = (int *)(db + o_drow);
-        fa.d_noise_old = (double *)(db + o_dnold);
-    }
-    const size_t lds = Np * 8 + unpack_lds_bytes() + 32;
-    hipLaunchKernelGGL(k_fd_unpack, dim3(B), dim3(FB), lds, st, fa);
-    HIPCHK(c, hipGetLastError());
-
-    const int Nx = (int)c->Nx;
-    const int tbins = tile_bins(c->wgs, c->K);
-    const int ntiles = (Nx + tbins - 1) / tbins;
-    const size_t nS = windowed ? (size_t)C + B : (size_t)B;
-    HIPCHK(c, c->d_part.reserve(nS * ntiles * 2));
+    const size_t nS = fb.nS;
+    HIPCHK(c, c->d_part.reserve(nS * fb.ntiles * 2));
     HIPCHK(c, c->d_S.reserve(nS));
     HIPCHK(c, c->h_S.reserve(nS));
-    LoglikeArgs a;
-    a.x = c->dx.p; a.y = c->dy.p; a.logx = c->dlogx.p; a.Nx = Nx; a.ntiles = ntiles;
-    a.x0 = c->hx[0]; a.step = c->hx[1] - c->hx[0];
-    a.noise_stride = stride; a.model = nullptr;
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
-    if (!windowed) {
-        a.B = B;
-        a.mults = fa.T.mults; a.offsets = fa.T.pairs; a.noise = fa.T.noise; a.nharvey = fa.T.nh; a.nnoise = fa.T.nn;
-        a.partials = c->d_part.p;
-        if (c->precision == TAMCMC_PRECISION_FAST) {
-            HIPCHK(c, c->d_bg.reserve((size_t)B * ntiles * 8));
-            HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, c->d_bg.p, st));
-            a.bg_poly = c->d_bg.p;
-        }
-        HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, false, st));
-        HIPCHK(c, launch_finalize(c->d_part.p, B, ntiles, c->d_S.p, st));
-    } else {
-        // (1) the C base points: full evaluation, model rows kept
-        HIPCHK(c, c->d_model.reserve((size_t)C * Nx));
-        a.B = C;
-        a.mults = fa.T.mults; a.offsets = fa.Bs.pairs; a.noise = fa.Bs.noise; a.nharvey = fa.Bs.nh; a.nnoise = fa.Bs.nn;
-        a.partials = c->d_part.p; a.model = c->d_model.p;
-        if (c->precision == TAMCMC_PRECISION_FAST) {
-            HIPCHK(c, c->d_bg.reserve((size_t)C * ntiles * 8));
-            HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, c->d_bg.p, st));
-            a.bg_poly = c->d_bg.p;
-        }
-        HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, true, st));
-        HIPCHK(c, launch_finalize(c->d_part.p, C, ntiles, c->d_S.p, st));
-        // (2) the C*Nvars perturbed points: log-likelihood DIFFERENCES from the delta tables
-        LoglikeArgs d = a;
-        d.B = B; d.model = nullptr; d.bg_poly = nullptr;
-        d.mults = fa.D.mults; d.offsets = fa.D.pairs; d.noise = fa.D.noise; d.nharvey = fa.D.nh; d.nnoise = fa.D.nn;
-        d.partials = c->d_part.p + (size_t)C * ntiles * 2;
-        d.d_range = fa.d_range; d.d_flags = fa.d_flags; d.d_row = fa.d_row; d.d_noise_old = fa.d_noise_old; d.model0 = c->d_model.p;
-        HIPCHK(c, launch_loglike_delta(d, c->precision, c->wgs, c->K, st));
-        HIPCHK(c, launch_finalize(d.partials, B, ntiles, c->d_S.p + C, st));
-    }
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, st));
+    if (windowed) HIPCHK(c, c->d_model.reserve((size_t)C * c->Nx));
+    if (c->precision == TAMCMC_PRECISION_FAST) HIPCHK(c, c->d_bg.reserve((size_t)(windowed ? C : B) * fb.ntiles * 8));
+    rc = fb.enqueue(c, db, nullptr, c->d_part.p, c->d_S.p, c->d_model.p, c->d_bg.p, c->timing ? c->ev0 : nullptr, c->timing ? c->ev1 : nullptr);
+    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_S.p, c->d_S.p, nS * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(hb + in_bytes, db + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

@@ -116,7 +116,6 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
     if (s->cur->last_status != TAMCMC_OK) return s->cur->last_status;
     s->prop = std::make_unique<Model_def>(*s->cur);
     if (c->engine == 1) {
-        if (c->use_drift != 0) return TAMCMC_ERR_BAD_ARG;  // the Langevin drift runs on the host-driven engine
         s->dev = std::make_unique<DevSampler>();
         std::vector<int> idx(s->cur->get_index_to_relax());
         DevSamplerInit di;
@@ -126,6 +125,7 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
         di.priors = in.priors.a.data(); di.extra_priors = in.extra_priors.data(); di.Tcoefs = s->mala->Tcoefs.data();
         di.seed = c->seed; di.dN_mixing = (long)c->dN_mixing; di.chain_groups = c->chain_groups;
         di.swap_rule = g.MALA.swap_rule;
+        di.use_drift = c->use_drift ? 1 : 0; di.delta = c->delta; di.fd_step_rel = g.MALA.fd_step_rel;
         di.c0 = c->c0; di.epsilon1 = c->epsilon1; di.epsi2 = c->epsilon2; di.A1 = c->A1; di.target_acceptance = c->target_acceptance;
         int rc = s->dev->init(ctx, di);
         if (rc) return rc;

@@ -159,6 +159,39 @@ def test_langevin_drift_sampler(pkg, oracle, synth, ctx):
     assert np.all(np.abs(m0[fidx] - m1[fidx]) < 4 * np.maximum(s0[fidx], s1[fidx]))
 
 
+def test_device_langevin_engine_follows_the_host_engine(pkg, oracle, synth, ctx):
+    """use_drift = 1 on the device-resident engine (k_mala_settle / finite-difference batch / k_mala_test, dev_mala_impl.h): same Philox
+    streams and the same algorithm as the host engine (host_mala.cpp) -> the chains coincide to rounding, through the adaptation window
+    and the swaps, until a knife-edge decision; afterwards both still sample (acceptance in a sane range)."""
+    star = _star_with_data(pkg, oracle, synth, nx=4000, seed=5)
+    ctx.set_spectrum(star.x, star.y)
+    kw = dict(use_drift=1, nchains=5, lambda_temp=1.5, seed=21, Nt_learn=(20, 60), periods_learn=(1,), c0=3.0, dN_mixing=1)
+    h = pkg.Sampler(ctx, star, engine="host", **kw)
+    d = pkg.Sampler(ctx, star, engine="device", **kw)
+    n = 90
+    sh, th = h.run(n, stats=True)
+    sd1, td1 = d.run(50, stats=True)
+    sd2, td2 = d.run(n - 50, stats=True)             # a second call continues the same chains (gradients stay valid)
+    sd, td = np.concatenate([sd1, sd2]), np.concatenate([td1, td2])
+    # (the forward differences divide ~1e-12 rounding differences of the two engines' arithmetic by steps of ~1e-7 |theta|: the gradients,
+    # hence the proposals, agree to ~1e-6 relative, and the adaptation feeds that back)
+    dev = np.max(np.abs(sh - sd) / (np.abs(sh) + 1e-3), axis=(1, 2))
+    same = dev < 1e-4
+    first_div = n if same.all() else int(np.argmin(same))
+    assert first_div >= 40, f"engines diverge at iteration {first_div}: {dev[max(first_div - 3, 0):first_div + 2]}"
+    assert np.allclose(th[:first_div], td[:first_div], rtol=1e-5, atol=1e-3)
+    a, b = h.state(), d.state()
+    assert a["iteration"] == b["iteration"] == n and a["swap_attempts"] == b["swap_attempts"] == n - 1
+    if first_div == n:
+        mh, ch = h.get_proposal(1)
+        md, cd = d.get_proposal(1)
+        assert np.allclose(mh, md, rtol=1e-4) and np.allclose(ch, cd, rtol=1e-3, atol=1e-6 * np.abs(ch).max())
+    smp, _ = d.run(400)
+    acc = np.mean(np.any(smp[1:, 0] != smp[:-1, 0], axis=1))
+    assert 0.05 < acc < 0.98, acc
+    h.close(); d.close()
+
+
 def test_forty_chains_device_engine(pkg, oracle, synth, ctx):
     """BASELINE config 5 asks for 40 tempered chains; the reference caps Nchains at 24 (MALA.cpp:580-587), this build at 64."""
     star = _star_with_data(pkg, oracle, synth, nx=2048, seed=2)

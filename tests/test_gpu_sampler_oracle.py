@@ -115,3 +115,30 @@ def test_one_iteration_equals_the_oracle_at_the_headline_shape(pkg, oracle, c3, 
     assert swaps_seen["in"] >= 1 and swaps_seen["across"] >= 1 and swaps_seen["refused"] >= 1, swaps_seen
     assert (quirk_visible >= 1) == (swap_rule == 1)     # rule 0 stores logL + logPrior; rule 1 keeps B's old prior in the sum
     s.close()
+
+
+def test_langevin_at_the_headline_shape(pkg, oracle, c3):
+    """North star's named path at C3 size on the DEVICE engine: the forward-difference gradient that drives the Langevin proposal equals the
+    oracle's finite differences of the reference log-likelihood (same steps), and the sampler it drives accepts at a healthy rate after
+    its adaptation window and moves every chain."""
+    star, ctx = c3
+    # (1) gradient of the tempered log-likelihood at the star's parameters, three temperatures: device FD batch vs orc_fd_gradient
+    # steps of 1e-5 |theta| here (the sampler's default is 1e-7): the ORACLE's difference of two ~1e5-term sums carries ~1e-8 of rounding
+    # noise, i.e. ~1e-2 of a typical gradient component at the 1e-7 step; the device forms its differences term by term and does not
+    h = 1e-5 * np.maximum(np.abs(star.params[star.index_to_relax]), 1e-3)
+    T = np.array([1.0, LAM ** 7, LAM ** 19])
+    l0, g = ctx.fd_gradient(star.model_id, np.tile(star.params, (3, 1)), star.plength, star.index_to_relax, h, T)
+    for j in (0, 2):
+        st, l0o, go = oracle.fd_gradient(star.model_id, star.params, star.plength, star.index_to_relax, h, star.x, star.y, 1.0, T[j])
+        assert st == 0 and abs(l0[j] - l0o) <= 2e-11 * abs(l0o)
+        scale = np.maximum(np.abs(go), 1e-3 * np.abs(go).max())     # compare on the gradient's own scale
+        assert np.max(np.abs(g[j] - go) / scale) < 1e-3, np.max(np.abs(g[j] - go) / scale)
+    # (2) the sampler
+    s = pkg.Sampler(ctx, star, nchains=NCH, lambda_temp=LAM, engine="device", use_drift=1, seed=31, Nt_learn=(30, 230), periods_learn=(1,), dN_mixing=1,
+                    c0=2.0)
+    s.run(230, record=False)
+    smp, stt = s.run(150, stats=True)
+    acc = np.mean(np.any(smp[1:] != smp[:-1], axis=2), axis=0)
+    assert np.all(np.isfinite(stt)) and 0.1 < acc[0] < 0.9 and 0.1 < acc.mean() < 0.9, acc
+    assert all((smp[1:, m] != smp[:-1, m]).any() for m in range(NCH))
+    s.close()
