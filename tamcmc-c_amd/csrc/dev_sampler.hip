@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include "rgb_prestep.h"
 #include "dev_sampler.h"
 #include "kernels.h"
 #include "loglike_tile.h"
@@ -284,14 +285,19 @@ __device__ __forceinline__ void Lz_rows_wave(const DevSamplerArgs &a, int chain,
     }
 }
 
+__host__ __device__ inline bool is_rgb_model(int id) { return id == TAMCMC_MODEL_RGB_ASYMPT_AJ_APPWIDTH_V4_ID || id == TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4_ID; }
+
 // Proposal of iteration `it` for `chain` from the state in LDS (s_vars/s_params): x' = x + L z (MALA.cpp:348-355), L =
 // chol((Sigma+eps2) sigma) stored transposed, same Philox streams as the host engine; log-prior; params' -> multiplet table
 // written into slot `slot` of the likelihood kernel's input block.  Ends without a barrier.  (B): 256 threads.
 __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int chain, long it, int slot, double *pv, double *pp,
-                               double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, const double *lz = nullptr) {
+                               double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, const double *lz = nullptr,
+                               const rgb::Slice *rs = nullptr, int rb = 0) {
     const int Np = a.desc.Np, Nv = a.Nv, tid = threadIdx.x;
+    const bool rgb = is_rgb_model(a.desc.model_id);
     if (!lz) normals_into(a, chain, it, s_z);
-    unpack_begin(a.desc, U);
+    if (!rgb) unpack_begin(a.desc, U);
+    else __syncthreads();
     for (int i = tid; i < Nv; i += TB) {  // lane i owns row i: reads s_vars[i] only, every s_z[k]
         const double s = lz ? lz[i] : Lz_row(a, chain, i, s_z);
         const double v = s_vars[i] + 0.0 + s;
@@ -302,6 +308,66 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
     for (int k = tid; k < Nv; k += TB) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
     __syncthreads();
     for (int i = tid; i < Np; i += TB) pp[i] = s_params[i];
+    if (rgb) {
+        // red-giant models (ids 25 / 27): the table needs the mixed-mode solver -- the kernels enqueued right behind this launch
+        // (rgb_device_stage) build it.  Here: the log-prior (priors_calc.cpp:319-512; generic terms one per lane, summed by lane 0 in the
+        // reference's order) by wave 0 while wave 1 runs the scalar unpack of the proposal (rgb_unpack.h) into the group's workspace slice.
+        __shared__ rgb::Prep sP;
+        __shared__ rgb::RowIn sR;
+        __shared__ double s_w[40], s_noise[3 * TAMCMC_MAX_HARVEY + 4], s_lp;
+        __shared__ int32_t s_hn[2];
+        __shared__ int s_stp;
+        mt::xreal *terms = (mt::xreal *)U.poly;  // (the polynomial tables' LDS is not used by these models; xreal = double on the device)
+        const bool spread = a.desc.prior_class == 4 && (size_t)Np * sizeof(mt::xreal) <= sizeof(mt::PolyTab);
+        if (tid == 0) *U.status = TAMCMC_OK;
+        __syncthreads();
+        if (spread)
+            for (int i = tid; i < Np; i += TB) {
+                int st = TAMCMC_OK;
+                terms[i] = pr::generic_prior_term(s_params, Np, a.desc.priors, a.desc.priors_switch, i, &st);
+                if (st != TAMCMC_OK) *U.status = st;
+            }
+        __syncthreads();
+        if (tid == 0) {
+            int st = *U.status;
+            s_lp = (double)pr::prior_serial(a.desc.prior_class, s_params, a.desc.plength, Np, a.desc.priors, a.desc.priors_switch, a.desc.extra, &st,
+                                            spread ? terms : nullptr);
+            s_stp = st;
+        } else if ((tid >> 6) == 1) {
+            rgb::WaveLanes x;
+            x.w = s_w;
+            double fmin;
+            rgb::unpack_vector(x, s_params, a.desc.plength, rs->step, a.desc.model_id == TAMCMC_MODEL_RGB_ASYMPT_AJ_CTEWIDTH_V4_ID, rs->dense, sP, sR, s_noise,
+                               &s_hn[0], &s_hn[1], &fmin);
+        }
+        __syncthreads();
+        const double lp = s_lp;
+        const int stp = s_stp;
+        if (tid == 0 && (stp != TAMCMC_OK || lp == -INFINITY || isnan(lp))) {  // model_def.cpp:472,476-480 skips the model: nothing to solve
+            sP.Lp = 0; sP.Lg = 0; sP.status = stp != TAMCMC_OK ? stp : TAMCMC_ERR_BAD_ARG;
+            sR.status = sP.status; sR.Nfl0 = sR.Nfl2 = sR.Nfl3 = 0; sR.bias_n = 0;
+            s_noise[0] = 1.0;
+            s_hn[0] = 0; s_hn[1] = 1;
+        }
+        __syncthreads();
+        static_assert(sizeof(rgb::Prep) % 8 == 0 && sizeof(rgb::RowIn) % 8 == 0, "copied as doubles");
+        const double *src = (const double *)&sP;
+        double *dst = (double *)&rs->preps[rb];
+        for (int i = tid; i < (int)(sizeof(rgb::Prep) / 8); i += TB) dst[i] = src[i];
+        src = (const double *)&sR;
+        dst = (double *)&rs->rows[rb];
+        for (int i = tid; i < (int)(sizeof(rgb::RowIn) / 8); i += TB) dst[i] = src[i];
+        for (int i = tid; i < s_hn[1] && i < a.desc.stride; i += TB) a.noise[(size_t)slot * a.desc.stride + i] = s_noise[i];
+        if (tid == 0) {
+            rs->norm_bits[rb] = 0ull;
+            rs->nsol[rb] = 0;
+            a.nh[slot] = s_hn[0];
+            a.nn[slot] = s_hn[1];
+            *logPr_out = lp;
+            *status_out = stp;
+        }
+        return;
+    }
 
     // ---- log-prior, then params' -> multiplet table written into the likelihood kernel's input block ----
     TablePtrs T;
@@ -355,7 +421,7 @@ __device__ __forceinline__ int resolve_swap(const DevSamplerArgs &a, int A, doub
 template <bool PROPOSE>
 __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const long it, const int P, const int pending,
                                                const long rec, const int learn_pending, double *scratch, const int c_off,
-                                               const int nmain, const int pre_flags) {
+                                               const int nmain, const int pre_flags, const rgb::Slice rs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int Np = a.desc.Np, Nv = a.Nv, C = a.C;
     if ((int)blockIdx.x >= nmain) {
@@ -451,7 +517,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
     // ------------------------------------------------------------------ (1) propose iteration `it`
     propose_common(a, U, m, it, m, a.vars_prop + (size_t)Q * C * Nv + (size_t)m * Nv, a.params_prop + (size_t)Q * C * Np + (size_t)m * Np,
                    a.logPr_prop + Q * C + m, a.status_prop + Q * C + m, s_vars, s_params, s_z,
-                   (pre_flags & 1) ? a.lz + ((size_t)(it & 1) * C + m) * Nv : nullptr);
+                   (pre_flags & 1) ? a.lz + ((size_t)(it & 1) * C + m) * Nv : nullptr, &rs, (int)blockIdx.x);
 }
 
 // ===============================================================================================================
@@ -861,6 +927,8 @@ struct DevSampler::Impl {
     long armed_it = -1;
     int armed_q = 0;
 
+    bool rgb = false;  // ids 25 / 27: k_iterate leaves the table to the pre-step kernels (rgb_device_stage), lockstep scheme
+    int rgb_bmax = 0;  // chains per workspace slice (one slice per chain group)
     bool fused_ok = false;
     int fused_mode = -1, fused_K = 0;  // the geometry the (A) buffers were sized for
     int tile_rot = 0;  // launch-order hint of k_loglike (first near-field tile of chain 0's initial table)
@@ -921,7 +989,8 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(hipSetDevice(c->device));
     DevSamplerArgs &a = I.a;
     a.desc.model_id = in.model_id; a.desc.prior_class = in.prior_class; a.C = in.C; a.desc.Np = in.Np; a.Nv = in.Nv;
-    a.desc.per = mt::count_multiplets(in.model_id, in.plength);
+    I.rgb = is_rgb_model(in.model_id);
+    a.desc.per = I.rgb ? 0 : mt::count_multiplets(in.model_id, in.plength);
     I.h_plength.assign(in.plength, in.plength + 11);
     I.use_drift = in.use_drift != 0; I.delta = in.delta; I.fd_step_rel = in.fd_step_rel > 0 ? in.fd_step_rel : 1e-7;
     I.prior_class = in.prior_class; I.model_id = in.model_id;
@@ -930,6 +999,22 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     if (a.desc.per < 0) return TAMCMC_ERR_BAD_MODEL;
     a.desc.stride = in.plength[8] > 0 ? in.plength[8] : 1;
     if ((a.desc.stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
+    {
+        int G = in.chain_groups > 0 ? in.chain_groups : (in.C >= 8 ? 2 : 1);
+        // red giants: an iteration is a chain of four latency-bound launches per group (proposal + unpack, solver, rows, likelihood);
+        // four groups keep the GPU busy while three of them are in their short kernels (C5, 40 chains: 3.4 / 3.8 / 4.0 / 4.05 k
+        // iterations/s with 1 / 2 / 3 / 4 groups)
+        if (in.chain_groups <= 0 && I.rgb && in.C >= 16) G = 4;
+        if (G > 4) G = 4;
+        if (G > in.C) G = in.C;
+        I.G = G;
+    }
+    if (I.rgb) {
+        if (I.use_drift) return TAMCMC_ERR_BAD_MODEL;  // the finite-difference builder has no red-giant pre-step
+        I.rgb_bmax = (in.C + I.G - 1) / I.G;
+        int rc = rgb_device_prepare(c, I.rgb_bmax, I.G, in.plength, &a.desc.per, &a.desc.stride);  // one workspace slice per chain group
+        if (rc) return rc;
+    }
     a.desc.Nx = (int)c->Nx;
     a.desc.x_first = c->hx[0]; a.desc.x_last = c->hx[(size_t)c->Nx - 1]; a.desc.step = c->hx[1] - c->hx[0];
     a.pl = (long)in.likelihood_params;
@@ -967,7 +1052,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     // Cholesky workspace: LDS when (Nv^2 + Nv) doubles fit beside the iteration's own LDS, else global scratch
     I.lds_base = (Np + 2 * Nv + 1) * sizeof(double) + unpack_lds_bytes() + 32;
     I.lds_adapt = (Nv * Nv + Nv) * sizeof(double);
-    a.chol_in_lds = (I.lds_base + I.lds_adapt <= 156 * 1024) ? 1 : 0;
+    a.chol_in_lds = (I.lds_base + I.lds_adapt <= 150 * 1024) ? 1 : 0;  // (k_iterate also has ~6 KB of static LDS)
     if (!a.chol_in_lds) { DCHK(I.dalloc(&I.adapt_scratch, C * (Nv * Nv + Nv))); I.lds_adapt = 0; }
     if (I.lds_base + I.lds_adapt > 64 * 1024) {
         DCHK(hipFuncSetAttribute((const void *)k_iterate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(I.lds_base + I.lds_adapt)));
@@ -981,11 +1066,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     a.desc.poly = d_tab;
     for (int i = 0; i < 64; i++) { DCHK(hipEventCreate(&I.ev[i][0])); DCHK(hipEventCreate(&I.ev[i][1])); I.n_ev = i + 1; }
     {
-        int G = in.chain_groups > 0 ? in.chain_groups : (in.C >= 8 ? 2 : 1);
-        if (G < 1) G = 1;
-        if (G > 4) G = 4;
-        if (G > in.C) G = in.C;
-        I.G = G;
+        const int G = I.G;
         I.gst[0] = st;
         for (int g = 1; g < G; g++) DCHK(hipStreamCreateWithFlags(&I.gst[g], hipStreamNonBlocking));
         DCHK(hipEventCreateWithFlags(&I.ev_fork, hipEventDisableTiming));
@@ -1011,7 +1092,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
         f.bg = nullptr;
         // the candidate roles borrow the tile workgroup's LDS: a parameter vector too long for it keeps the lockstep scheme
         const size_t role_lds = (Np + 2 * Nv + 1) * sizeof(double) + unpack_lds_bytes() + 32;
-        I.fused_ok = role_lds <= sizeof(tile::TileLds<tile::M_FAST_DIRECT, 64>);
+        I.fused_ok = !I.rgb && role_lds <= sizeof(tile::TileLds<tile::M_FAST_DIRECT, 64>);
     }
     DCHK(hipStreamSynchronize(st));
     return TAMCMC_OK;
@@ -1038,7 +1119,13 @@ int DevSampler::upload_state(const double *vars, const double *params, const dou
         int n = 0, nh = 0, nn = 0;
         const int tb = tile_bins(c->wgs, c->K);
         I.tile_rot = 0;
-        if (build_mode_table(a.desc.model_id, params, I.h_plength.data(), c->hx.data(), c->Nx, tab.data(), a.desc.per, &n, nz.data(), &nh, &nn) == TAMCMC_OK && n <= a.desc.per)
+        if (I.rgb) {  // a little below the lowest radial mode (rgb_stage_params' rule)
+            const double *fl0 = params + I.h_plength[0] + I.h_plength[1];
+            const double fmin = *std::min_element(fl0, fl0 + I.h_plength[2]);
+            const int ntiles = (int)((c->Nx + tb - 1) / tb);
+            const double t = (fmin - a.desc.x_first) / a.desc.step / (double)tb - 3.0;
+            I.tile_rot = (t > 0 && t < ntiles) ? (int)t : 0;
+        } else if (build_mode_table(a.desc.model_id, params, I.h_plength.data(), c->hx.data(), c->Nx, tab.data(), a.desc.per, &n, nz.data(), &nh, &nn) == TAMCMC_OK && n <= a.desc.per)
             I.tile_rot = pick_tile_rot(tab.data(), n, a.desc.x_first, a.desc.step, tb, (int)((c->Nx + tb - 1) / tb));
     }
     return TAMCMC_OK;
@@ -1261,10 +1348,10 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
                 const int cnt = goff[g + 1] - goff[g];
                 if (i < ib)
                     hipLaunchKernelGGL(k_iterate<true>, dim3(make_pre ? 2 * cnt : cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p,
-                                       I.adapt_scratch, goff[g], cnt, pre_flags);
+                                       I.adapt_scratch, goff[g], cnt, pre_flags, I.rgb ? rgb_device_slice(c, I.rgb_bmax, g) : rgb::Slice());
                 else  // settle the last iteration of this stretch (MH test, swap, record, adaptation); nothing is proposed
                     hipLaunchKernelGGL(k_iterate<false>, dim3(cnt), dim3(TB), lds, I.gst[g], args, it, P, pending, rec, learn_p, I.adapt_scratch,
-                                       goff[g], cnt, 0);
+                                       goff[g], cnt, 0, rgb::Slice());
             }
             have_pre = make_pre;
             if (gA >= 0) {  // ... and must not overwrite (next iteration) what the other group's settle is still reading
@@ -1275,6 +1362,16 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             }
             P ^= 1;
             pending = 1;
+            if (i < ib && I.rgb) {  // the proposals' tables: solver, then sort / zeta / rows (and the FAST background series)
+                RgbDeviceTables T;
+                T.mults = a.mults; T.pairs = a.pairs; T.nh = a.nh; T.nn = a.nn; T.noise = a.noise; T.stride = a.desc.stride;
+                T.status = a.status_prop + (size_t)P * C;
+                T.bg = a.bg; T.ntiles = a.ntiles; T.tile_bins = a.tile_bins;
+                for (int g = 0; g < G; g++) {
+                    int rc = rgb_device_stage(c, goff[g], goff[g + 1] - goff[g], I.rgb_bmax, g, a.desc.per, T, I.gst[g]);
+                    if (rc) return rc;
+                }
+            }
             if (i < ib) {
                 for (int g = 0; g < G; g++) {
                     const bool timed = g == 0 && c->timing && ((i - ia) % ev_every == 0) && used_ev < I.n_ev - 16;  // (the top 16 pairs: fused stretches)

@@ -215,8 +215,9 @@ TM_HD xreal local_constraints(const double *params, const int *pl, const int *sw
 }
 
 // ---- serial evaluation in the reference's order (host; also usable on the device by one thread) ----
+// generic_terms (class 4): the Np generic prior terms already evaluated (the device spreads them over lanes; summed here in the same order)
 TM_HD xreal prior_serial(int prior_class, const double *params, const int *pl, long Np, const double *pp, const int *sw,
-                         const double *extra, int *status) {
+                         const double *extra, int *status, const xreal *generic_terms = nullptr) {
     xreal f = 0;
     if (prior_class == 2) {
         const xreal c = ms_global_constraints(params, pl, sw, extra, status);
@@ -249,7 +250,7 @@ TM_HD xreal prior_serial(int prior_class, const double *params, const int *pl, l
         if ((sw[Nmax + lmax + Nf + 9] != 0) && (params[on + 9] < 0)) return neg_inf();  // index as in priors_calc.cpp:391
         for (int i = i0; i < i0 + Nwidth; i++)
             if (sw[i] == 2 && params[i] < 0) return neg_inf();  // Gaussian priors on the width law: positive support only
-        for (long i = 0; i < Np; i++) f = f + generic_prior_term(params, Np, pp, sw, i, status);
+        for (long i = 0; i < Np; i++) f = f + (generic_terms ? generic_terms[i] : generic_prior_term(params, Np, pp, sw, i, status));
         if (model_switch == 1) {  // the v3 models (l=1 p-mode list in the parameter vector): not built here
             if (status) *status = TAMCMC_ERR_BAD_MODEL;
             return neg_inf();

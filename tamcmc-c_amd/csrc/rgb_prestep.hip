@@ -29,37 +29,17 @@
 #include "mode_tables.h"
 #include "mode_tables_impl.h"
 #include "rgb_prestep.h"
+#include "rgb_unpack.h"
+#include "bg_series.h"
 #include "kernels.h"
 
 namespace tamcmc {
 const mt::PolyTab &poly_table();  // mode_tables.cpp
 namespace rgb {
 
-constexpr int MAXP = 32;      // p modes per vector (fmax-fmin+2 Dnu)/Dnu + margins
-constexpr int MAXSOL = 1024;  // mixed modes per vector before de-duplication
 constexpr int WG = 256;
+constexpr int SOLVE_NT = 256;  // lanes per (vector, p mode) workgroup of the solver
 
-struct Prep {  // one parameter vector's solver inputs
-    int Lp, Lg, ng_min, status;
-    int probe_dense, pad_;         // TAMCMC_OPT_ARMM_DENSE_SCAN: walk the whole grid (the reference's way) instead of the pole-structured scan
-    int ig0[MAXP];                 // first g mode inside the zone of p mode ip, -1: none (the reference skips the pair)
-    double nu_p[MAXP], dnu_loc[MAXP], dnup[MAXP];
-    double Dnu_p, DPl, alpha, q, zone, resol, fact, keep_lo, keep_hi;
-};
-
-constexpr int MAXL = 32;       // modes per degree listed in the parameter vector
-constexpr int MAXNODE = 16;    // nodes of the bias spline
-constexpr int CAP1 = 400;      // mixed modes per vector that get a table row
-
-struct RowIn {  // everything the row builder needs besides the solver's output (host-filled, one per vector)
-    int Nfl0, Nfl2, Nfl3, lmax, do_amp, bias_n, status, cte_width;  // cte_width: id 27, every width is g[0]
-    double fl0[MAXL], Wl0[MAXL], Hl0[MAXL], fl2[MAXL], fl3[MAXL];
-    double g[6], Vl[4], V[4][7];
-    double eta0, asym, trunc_c, Hfactor, Wfactor, rot_env, rot_core, a2, a3, a4, a5, a6, fmin, fmax;
-    double sx[MAXNODE], sy[MAXNODE], sb[MAXNODE], sc[MAXNODE], sd[MAXNODE], sc0;  // spline coefficients (host-computed), bias_n nodes
-};
-
-__host__ __device__ inline double nu_g_of(const Prep &p, int ig) { return 1e6 / (((double)(p.ng_min + ig) + p.alpha) * p.DPl); }
 
 namespace {
 
@@ -85,8 +65,9 @@ __device__ __forceinline__ bool changes_sign(double a, double b) {  // sign_chan
 //          y = nu at 0 (interpol.cpp:13-43), the 0.1 % ratio test.  Without a pole inside the window p-g is increasing there and the
 //          bracketing pair is found by bisection; the rare windows that hold both a bracket and a pole are walked point by point by
 //          the whole wave afterwards, like the reference does.
-__global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sols, int *nsol) {
-    const int b = blockIdx.y, ip = blockIdx.x, lane = threadIdx.x;
+__device__ void armm_scan_pair(const Prep *preps, double *sols, int *nsol) {
+    const int b = blockIdx.y, ip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = SOLVE_NT, NW = NT / 64;
     const Prep &P = preps[b];
     if (ip >= P.Lp || P.status != 0 || P.ig0[ip] < 0) return;
     const double nu_p = P.nu_p[ip], Dl = P.dnu_loc[ip], nu_g = nu_g_of(P, P.ig0[ip]);
@@ -103,7 +84,7 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
     __shared__ long s_cand[MAXC];
     __shared__ int s_hard[MAXC];
     __shared__ int s_nc, s_nh;
-    if (lane == 0) { s_nc = 0; s_nh = 0; }
+    if (tid == 0) { s_nc = 0; s_nh = 0; }
     __syncthreads();
     auto push = [&](long i) {
         const int k = atomicAdd(&s_nc, 1);
@@ -122,15 +103,30 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
             if (!(c < (double)(n + 1))) c = (double)(n + 1);
             return (long)c;
         };
-        for (long u = lane; u <= np; u += 64) {
+        // two work items per unit, one LANE each: (odd) the cells around pole u-1, (even) the pole-free stretch of unit u
+        for (long w = tid; w <= 2 * np + 1; w += NT) {
+            const long u = w >> 1;
+            if (w & 1) {
+                if (u == 0) continue;
+                const long j = u - 1, cj = pole_cell(j);
+                const long prev_end = (j > 0) ? pole_cell(j - 1) + 1 : -1;  // last cell of the previous pole's zone
+                long i = (cj - 1 > prev_end ? cj - 1 : prev_end + 1);
+                const long i_end = cj + 1 < n - 2 ? cj + 1 : n - 2;
+                if (i < 0) i = 0;
+                if (i > i_end) continue;
+                double fa = fg(i);  // each point of the run is evaluated once (the right end of a cell is the left end of the next)
+                for (; i <= i_end; i++) {
+                    const double fb = fg(i + 1);
+                    if (changes_sign(fa, fb)) push(i);
+                    fa = fb;
+                }
+                continue;
+            }
             long a, e;  // the pole-free stretch of this unit: cells with left index a .. e
             if (u == 0) { a = 0; e = pole_cell(0) - 2; }
             else {
-                const long j = u - 1, cj = pole_cell(j);
-                const long prev_end = (j > 0) ? pole_cell(j - 1) + 1 : -1;  // last cell of the previous pole's zone
-                for (long i = (cj - 1 > prev_end ? cj - 1 : prev_end + 1); i <= cj + 1; i++)
-                    if (i >= 0 && i <= n - 2 && changes_sign(fg(i), fg(i + 1))) push(i);
-                a = cj + 2;
+                const long j = u - 1;
+                a = pole_cell(j) + 2;
                 e = (j + 1 < np) ? pole_cell(j + 1) - 2 : n - 2;
             }
             if (a < 0) a = 0;
@@ -148,8 +144,8 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
         }
     } else {
         // dense walk: each lane evaluates ONE point per pass; its right neighbour's value comes from the next lane (lane 63
-        // evaluates that one point more)
-        for (long i0 = 0; i0 < n - 1; i0 += 64) {
+        // of each wave evaluates that one point more)
+        for (long i0 = (long)wave * 64; i0 < n - 1; i0 += NT) {
             const long i = i0 + lane;
             const double fa = (i < n) ? fg(i) : 0.0;
             double fb = __shfl_down(fa, 1, 64);
@@ -159,7 +155,7 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
     }
     __syncthreads();
     if (s_nc > MAXC) {  // more sign changes than the candidate list holds: flag the vector (the host reports it), do not guess
-        if (lane == 0) atomicAdd(&nsol[b], 2 * MAXSOL);
+        if (tid == 0) atomicAdd(&nsol[b], 2 * MAXSOL);
         return;
     }
     const int nc = s_nc;
@@ -177,14 +173,13 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
     };
     auto lg = [&](const Local &L, long j) { return (j == L.nl - 1) ? L.rmax : L.rmin + (double)j * L.ls; };
     auto fl = [&](const Local &L, long j) { return f_pg(lg(L, j), nu_p, nu_g, Dl, P.DPl, P.q); };
-    // straight line through two local points evaluated at p-g = 0, then the ratio test (solver_mm.cpp:392-404)
-    auto finish = [&](const Local &L, long best, double f_first, double f_last) {
+    // straight line through two local points evaluated at p-g = 0, then the ratio test (solver_mm.cpp:392-404).  (j, fa, fb): the
+    // bracketing pair lin_interpol uses when it interpolates and the function there (values the search already holds)
+    auto finish = [&](const Local &L, long j, double fa_j, double fb_j, double f_first, double f_last) {
         double a = 0, bb = 0;
         if (0.0 >= f_first && 0.0 <= f_last) {
-            const long j = best < L.nl - 1 ? best : L.nl - 2;
-            const double fa = fl(L, j), fb = fl(L, j + 1);
-            a = (lg(L, j + 1) - lg(L, j)) / (fb - fa);
-            bb = lg(L, j) - a * fa;
+            a = (lg(L, j + 1) - lg(L, j)) / (fb_j - fa_j);
+            bb = lg(L, j) - a * fa_j;
         }
         if (0.0 < f_first) {
             a = (lg(L, 1) - lg(L, 0)) / (fl(L, 1) - f_first);
@@ -204,17 +199,18 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
             if (k < MAXSOL) sols[(size_t)b * MAXSOL + k] = prop;
         }
     };
-    for (int c = lane; c < nc; c += 64) {
+    for (int c = tid; c < nc; c += NT) {
         const Local L = local_of(s_cand[c]);
         if (L.nl < 2) continue;
         const double f_first = fl(L, 0), f_last = fl(L, L.nl - 1);
         // first j with f[j] <= 0 <= f[j+1] -- only needed when lin_interpol interpolates (f_first <= 0 <= f_last); otherwise it
         // extrapolates from the first or last two points (a pole of tan(): half of all candidates) and no search is made
-        long best = L.nl;
+        long best = 0;
+        double f_lo = f_first, f_hi = f_last;
         if (!(0.0 < f_first) && !(0.0 > f_last)) {
             const double ka = kap_scale * (1. / L.rmin - inv_g) - 0.5, kb = kap_scale * (1. / L.rmax - inv_g) - 0.5;
             const bool pole_inside = (floor(ka) != floor(kb)) || fabs(ka - rint(ka)) < 1e-9 || fabs(kb - rint(kb)) < 1e-9;
-            if (pole_inside) {  // left to the whole wave below
+            if (pole_inside) {  // left to a whole wave below
                 const int k = atomicAdd(&s_nh, 1);
                 s_hard[k] = c;
                 continue;
@@ -222,17 +218,22 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
             long lo_j = 0, hi_j = L.nl - 1;  // f[lo_j] <= 0 <= f[hi_j], p-g increasing: the last point with f <= 0
             while (hi_j - lo_j > 1) {
                 const long mid = lo_j + (hi_j - lo_j) / 2;
-                if (fl(L, mid) <= 0.0) lo_j = mid; else hi_j = mid;
+                const double fm = fl(L, mid);
+                if (fm <= 0.0) { lo_j = mid; f_lo = fm; } else { hi_j = mid; f_hi = fm; }
             }
             // step back over exact zeros so that the FIRST pair with f[j] <= 0 <= f[j+1] is the one used
             best = lo_j;
-            while (best > 0 && fl(L, best - 1) <= 0.0 && fl(L, best) >= 0.0 && !(fl(L, best) > 0.0)) best--;
+            while (best > 0 && f_lo == 0.0) {
+                const double fp = fl(L, best - 1);
+                if (!(fp <= 0.0)) break;
+                best--; f_hi = f_lo; f_lo = fp;
+            }
         }
-        finish(L, best, f_first, f_last);
+        finish(L, best, f_lo, f_hi, f_first, f_last);
     }
     __syncthreads();
     const int nh = s_nh;
-    for (int hc = 0; hc < nh; hc++) {  // wave-uniform
+    for (int hc = wave; hc < nh; hc += NW) {  // wave-uniform: one wave per window, the reference's point-by-point walk
         const Local L = local_of(s_cand[s_hard[hc]]);
         const double f_first = fl(L, 0), f_last = fl(L, L.nl - 1);
         long best = L.nl;
@@ -246,43 +247,67 @@ __global__ void __launch_bounds__(64) k_armm_scan(const Prep *preps, double *sol
             const unsigned long long m = __ballot(hit);
             if (m) { best = j0 + (long)(__ffsll((long long)m) - 1); break; }
         }
-        if (lane == 0) finish(L, best, f_first, f_last);
+        if (lane == 0) {
+            const long j = best < L.nl - 1 ? best : L.nl - 2;
+            finish(L, j, fl(L, j), fl(L, j + 1), f_first, f_last);
+        }
     }
 }
 
-// One workgroup per vector: bitonic sort of its solutions, then std::unique with |a-b| <= 2 resol (solver_mm.cpp:586-593).
-__global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, const RowIn *rows_in, double *sols, int *nsol, double *fl1) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    __shared__ double s[MAXSOL];
-    if (nsol[b] > MAXSOL) return;  // overflow flag: left for the host
-    const int n = nsol[b];
-    int N2 = 64;  // bitonic network over the next power of two (padding sorts to the end)
-    while (N2 < n) N2 <<= 1;
-    for (int i = tid; i < N2; i += WG) s[i] = i < n ? sols[(size_t)b * MAXSOL + i] : INFINITY;
+// One workgroup per vector: its solutions sorted, then std::unique with |a-b| <= 2 resol (solver_mm.cpp:586-593).
+// (part of k_rgb_finish; every lane of the workgroup runs through it).  The result is left in s[0 .. *s_m_p).
+__device__ void sort_unique_bias(const int b, const Prep *preps, const RowIn *rows_in, double *sols, int *nsol, double *fl1, double *s /* LDS [MAXSOL] */,
+                                 double *t /* LDS [MAXSOL] */, unsigned char *keep /* LDS [MAXSOL] */, int *s_m_p /* LDS */) {
+    const int tid = threadIdx.x;
+    int &s_m = *s_m_p;
+    const int n_raw = nsol[b];
+    const int n = (n_raw > MAXSOL || n_raw < 0) ? 0 : n_raw;  // overflow: the count stays as it is, the row builder refuses the vector
+    for (int i = tid; i < n; i += WG) s[i] = sols[(size_t)b * MAXSOL + i];
+    __syncthreads();                                          // (every lane has read nsol[b] before lane 0 rewrites it)
+    // sort by rank: element i goes to the number of elements that sort before it (ties by index); LDS broadcast reads, no barrier per stage
+    for (int i = tid; i < n; i += WG) {
+        const double v = s[i];
+        int r = 0;
+        for (int j = 0; j < n; j++) {
+            const double u = s[j];
+            r += (u < v || (u == v && j < i)) ? 1 : 0;
+        }
+        t[r] = v;
+    }
     __syncthreads();
-    for (int k = 2; k <= N2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < N2; i += WG) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const double a = s[i], c = s[l];
-                    if ((a > c) == up) { s[i] = c; s[l] = a; }
-                }
-            }
-            __syncthreads();
+    // std::unique keeps an element unless it is within tol of the last KEPT one.  An element further than tol from its left neighbour
+    // is always kept (the last kept one is not larger than that neighbour), so the chain restarts there: one lane per such run.
+    const double tol = 2 * preps[b].resol;
+    for (int i = tid; i < n; i += WG) {
+        if (i > 0 && fabs(t[i - 1] - t[i]) <= tol) continue;  // not the head of a run
+        double last = t[i];
+        keep[i] = 1;
+        for (int j = i + 1; j < n && fabs(t[j - 1] - t[j]) <= tol; j++) {
+            const double v = t[j];
+            if (!(fabs(last - v) <= tol)) { keep[j] = 1; last = v; } else keep[j] = 0;
         }
-    __shared__ int s_m;
-    if (tid == 0) {  // std::unique keeps an element unless it is within tol of the last KEPT one: a serial chain, run in LDS (in place)
-        const double tol = 2 * preps[b].resol;
-        int m = 0;
-        double last = 0;
-        for (int i = 0; i < n; i++) {
-            const double v = s[i];
-            if (m == 0 || !(fabs(last - v) <= tol)) { s[m++] = v; last = v; }
+    }
+    __syncthreads();
+    {   // compaction: exclusive prefix sum of the keep flags, 4 consecutive elements per lane
+        __shared__ int s_wsum[WG / 64];
+        const int base = tid * 4;
+        int k4[4], mine = 0;
+        for (int q = 0; q < 4; q++) { k4[q] = (base + q < n) ? keep[base + q] : 0; mine += k4[q]; }
+        int inc = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(inc, off, 64);
+            if ((tid & 63) >= off) inc += up;
         }
-        nsol[b] = m;
-        s_m = m;
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = inc;
+        __syncthreads();
+        int pos = inc - mine;
+        for (int w = 0; w < (tid >> 6); w++) pos += s_wsum[w];
+        for (int q = 0; q < 4; q++)
+            if (k4[q]) s[pos++] = t[base + q];
+        if (tid == WG - 1) {
+            s_m = pos;
+            if (n_raw == n) nsol[b] = pos;
+        }
     }
     __syncthreads();
     for (int i = tid; i < s_m; i += WG) sols[(size_t)b * MAXSOL + i] = s[i];
@@ -303,6 +328,7 @@ __global__ void __launch_bounds__(WG) k_armm_sort_unique(const Prep *preps, cons
         }
         fl1[(size_t)b * MAXSOL + i] = v + bias;
     }
+    __syncthreads();
 }
 
 // One (p, g) term of the zeta function (bump_DP.cpp:46-78):
@@ -326,14 +352,12 @@ __device__ __forceinline__ double ksi_sum(const Prep &P, double nu) {
     return s;
 }
 
-// grid (chunks, B): un-normalised zeta at the vector's modes (chunk 0) and the maximum of the same sum over the high-resolution grid
-__global__ void __launch_bounds__(WG) k_zeta(const Prep *preps, const double *fl1, const int *n1, double *ksi, unsigned long long *norm_bits,
-                                             int chunks) {
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const Prep &P = preps[b];
-    if (P.status != 0 || P.Lp < 1 || P.Lg < 1) return;  // failed vector, or no g mode in range (no mixed modes)
-    if (blockIdx.x == 0)
-        for (int i = tid; i < n1[b]; i += WG) ksi[(size_t)b * MAXSOL + i] = ksi_sum(P, fl1[(size_t)b * MAXSOL + i]);
+// Maximum of the same sum over the high-resolution grid (the normalisation of zeta, bump_DP.cpp:125-188), chunk `chunk` of `chunks`
+// by one workgroup of NT lanes; the maximum does not depend on how the grid is cut.
+template <int NT>
+__device__ void zeta_norm_chunk(const Prep &P, int chunk, int chunks, unsigned long long *norm_bits_b) {
+    const int tid = threadIdx.x;
+    if (P.status != 0 || P.Lp < 1 || P.Lg < 1) return;  // failed vector, or no g mode in range (no mixed modes); workgroup-uniform
     double pmin = P.nu_p[0], pmax = P.nu_p[0];
     for (int i = 1; i < P.Lp; i++) { pmin = fmin(pmin, P.nu_p[i]); pmax = fmax(pmax, P.nu_p[i]); }
     const double gmax = nu_g_of(P, 0), gmin = nu_g_of(P, P.Lg - 1);  // the g ladder decreases with n_g
@@ -343,29 +367,72 @@ __global__ void __launch_bounds__(WG) k_zeta(const Prep *preps, const double *fl
     double best = 0;
     if (nh >= 2) {
         const double step = (hi - lo) / (double)(nh - 1);
-        for (long i = (long)blockIdx.x * WG + tid; i < nh; i += (long)chunks * WG) {
+        for (long i = (long)chunk * NT + tid; i < nh; i += (long)chunks * NT) {
             const double v = ksi_sum(P, (i == nh - 1) ? hi : lo + (double)i * step);
             if (v > best) best = v;
         }
     }
     // one atomic per workgroup (atomics on one address serialise in L2)
-    __shared__ double s_best[WG / 64];
+    __shared__ double s_best[NT / 64];
     for (int off = 32; off >= 1; off >>= 1) best = fmax(best, __shfl_down(best, off, 64));
     if ((tid & 63) == 0) s_best[tid >> 6] = best;
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < WG / 64; w++) best = fmax(best, s_best[w]);
-        if (best > 0) atomicMax(&norm_bits[b], (unsigned long long)__double_as_longlong(best));  // positive doubles order as integers
+        for (int w = 1; w < NT / 64; w++) best = fmax(best, s_best[w]);
+        if (best > 0) atomicMax(norm_bits_b, (unsigned long long)__double_as_longlong(best));  // positive doubles order as integers
     }
+}
+
+// grid (MAXP + ZCHUNKS, B), SOLVE_NT lanes: blocks [0, MAXP) solve one p mode each (armm_scan_pair), the others take a chunk of the zeta
+// normalisation grid -- it needs the vector's ladders only, not the roots, so it runs beside the solver instead of after it.
+constexpr int ZCHUNKS = 16;
+__global__ void __launch_bounds__(SOLVE_NT) k_armm_solve(const Prep *preps, double *sols, int *nsol, unsigned long long *norm_bits) {
+    const int b = blockIdx.y;
+    if ((int)blockIdx.x < MAXP) armm_scan_pair(preps, sols, nsol);
+    else zeta_norm_chunk<SOLVE_NT>(preps[b], (int)blockIdx.x - MAXP, ZCHUNKS, norm_bits + b);
 }
 
 // One workgroup per vector: the table rows (l=0 list, mixed modes, l=2, l=3 lists) written into the likelihood kernel's input block,
 // in the reference's accumulation order (models.cpp:4915-5000); mixed-mode scalars: bump_DP.cpp:203-254, :531-547.
-__global__ void __launch_bounds__(WG) k_rgb_rows(const Prep *preps, const RowIn *rows_in, const mt::PolyTab *poly, const double *fl1, const int *n1,
-                                                 const double *ksi, const unsigned long long *norm_bits, double x_first, double x_last, long Nx,
-                                                 double step, int per, tamcmc_multiplet *mults, int *pairs, int *status) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+struct BgOut {  // optional by-product of k_rgb_finish: the FAST far-field background series of the vector's tiles ([chain][tile][NH])
+    double *out = nullptr;
+    const double *noise = nullptr;
+    const int *nh = nullptr, *nn = nullptr;
+    int stride = 0, ntiles = 0, tile_bins = 0;
+    double x0 = 0, step = 0;
+};
+
+// One workgroup per vector, after k_armm_solve: sort + unique of the roots and their spline bias, zeta at the modes, then the rows.
+// b0: the engine-side arrays (mults, pairs, status) are indexed by b0 + b (a chain group of the device engine works on chains b0..),
+// the workspace arrays by b.
+__global__ void __launch_bounds__(WG) k_rgb_finish(const Prep *preps, const RowIn *rows_in, const mt::PolyTab *poly, double *sols, int *n1, double *fl1,
+                                                   double *ksi, const unsigned long long *norm_bits, double x_first, double x_last, long Nx,
+                                                   double step, int per, int b0, tamcmc_multiplet *mults, int *pairs, int *status, const BgOut bg) {
+    const int b = blockIdx.x, tid = threadIdx.x, e = b0 + b;
     const RowIn &R = rows_in[b];
+    if (bg.out) {  // the vector's background series per likelihood tile (k_bg_poly's arithmetic; the noise row is in place since the proposal kernel)
+        const int nn = bg.nn[e];
+        const double *nz = bg.noise + (size_t)e * bg.stride;
+        for (int tile = tid; nn > 0 && tile < bg.ntiles; tile += WG) {
+            double xc, h;
+            bg::tile_geometry(tile, bg.tile_bins, bg.x0, bg.step, xc, h);
+            if (!bg::series_valid(xc, h)) continue;
+            double o[bg::NH];
+            bg::tile_series([nz](int i) { return nz[i]; }, bg.nh[e], nn, xc, h, o);
+            for (int k = 0; k < bg::NH; k++) bg.out[((size_t)e * bg.ntiles + tile) * bg::NH + k] = o[k];
+        }
+    }
+    static_assert(MAXSOL <= 4 * WG, "the compaction handles 4 elements per lane");
+    __shared__ double s_sol[MAXSOL], s_tmp[MAXSOL];
+    __shared__ unsigned char s_keep[MAXSOL];
+    __shared__ int s_m;
+    sort_unique_bias(b, preps, rows_in, sols, n1, fl1, s_sol, s_tmp, s_keep, &s_m);
+    {   // un-normalised zeta at the vector's modes
+        const Prep &P = preps[b];
+        if (!(P.status != 0 || P.Lp < 1 || P.Lg < 1))
+            for (int i = tid; i < s_m; i += WG) ksi[(size_t)b * MAXSOL + i] = ksi_sum(P, fl1[(size_t)b * MAXSOL + i]);
+    }
+    __syncthreads();
     __shared__ double s_fi[MAXL + 4], s_hi[MAXL + 4];
     __shared__ int s_st;
     if (tid == 0) s_st = (R.status != 0 || preps[b].status != 0) ? (R.status ? R.status : preps[b].status) : 0;
@@ -419,7 +486,7 @@ __global__ void __launch_bounds__(WG) k_rgb_rows(const Prep *preps, const RowIn 
             a[1] = R.rot_env; a[2] = R.a2; a[3] = R.a3; a[4] = R.a4;
             if (!is2) { a[5] = R.a5; a[6] = R.a6; }
         }
-        tamcmc_multiplet *r = &mults[(size_t)b * per + k];
+        tamcmc_multiplet *r = &mults[(size_t)e * per + k];
         int i0 = 0, i1 = 0;
         const int rs = mt::set_imin_imax(x_first, x_last, Nx, l, f, W, a[1], R.trunc_c, step, &i0, &i1);
         if (rs) { s_st = rs; continue; }
@@ -433,198 +500,14 @@ __global__ void __launch_bounds__(WG) k_rgb_rows(const Prep *preps, const RowIn 
     __syncthreads();
     if (tid == 0) {
         const bool good = (s_st == 0);
-        pairs[2 * b] = b * per;
-        pairs[2 * b + 1] = good ? b * per + total : b * per;
-        status[b] = s_st;
+        pairs[2 * e] = e * per;
+        pairs[2 * e + 1] = good ? e * per + total : e * per;
+        status[e] = s_st;
     }
 }
 
 __global__ void k_fill_poly_rgb(mt::PolyTab *t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) mt::fill_poly(*t);
-}
-
-// ---------------------------------------------------------------- host side
-struct Spline {  // natural cubic (type 1) or cubic Hermite (type 2) through the bias nodes, spline.h:242-498
-    std::vector<double> x, y, b, c, d;
-    double c0 = 0;
-    bool set(const double *xn, const double *yn, int n, int type) {
-        if (n < 3) return false;
-        for (int i = 0; i < n - 1; i++)
-            if (!(xn[i] < xn[i + 1])) return false;
-        x.assign(xn, xn + n); y.assign(yn, yn + n); b.assign((size_t)n, 0); c.assign((size_t)n, 0); d.assign((size_t)n, 0);
-        if (type == 1) {
-            std::vector<double> sub((size_t)n, 0), dia((size_t)n, 2.0), sup((size_t)n, 0), rhs((size_t)n, 0);
-            for (int i = 1; i < n - 1; i++) {
-                sub[(size_t)i] = (x[(size_t)i] - x[(size_t)i - 1]) / 3.0;
-                dia[(size_t)i] = 2.0 / 3.0 * (x[(size_t)i + 1] - x[(size_t)i - 1]);
-                sup[(size_t)i] = (x[(size_t)i + 1] - x[(size_t)i]) / 3.0;
-                rhs[(size_t)i] = (y[(size_t)i + 1] - y[(size_t)i]) / (x[(size_t)i + 1] - x[(size_t)i]) -
-                                 (y[(size_t)i] - y[(size_t)i - 1]) / (x[(size_t)i] - x[(size_t)i - 1]);
-            }
-            for (int i = 1; i < n; i++) {
-                const double w = sub[(size_t)i] / dia[(size_t)i - 1];
-                dia[(size_t)i] -= w * sup[(size_t)i - 1];
-                rhs[(size_t)i] -= w * rhs[(size_t)i - 1];
-            }
-            c[(size_t)n - 1] = rhs[(size_t)n - 1] / dia[(size_t)n - 1];
-            for (int i = n - 2; i >= 0; i--) c[(size_t)i] = (rhs[(size_t)i] - sup[(size_t)i] * c[(size_t)i + 1]) / dia[(size_t)i];
-            for (int i = 0; i < n - 1; i++) {
-                const double h = x[(size_t)i + 1] - x[(size_t)i];
-                d[(size_t)i] = (c[(size_t)i + 1] - c[(size_t)i]) / (3.0 * h);
-                b[(size_t)i] = (y[(size_t)i + 1] - y[(size_t)i]) / h - (2.0 * c[(size_t)i] + c[(size_t)i + 1]) * h / 3.0;
-            }
-            const double h = x[(size_t)n - 1] - x[(size_t)n - 2];
-            b[(size_t)n - 1] = 3.0 * d[(size_t)n - 2] * h * h + 2.0 * c[(size_t)n - 2] * h + b[(size_t)n - 2];
-        } else {
-            for (int i = 1; i < n - 1; i++) {
-                const double h = x[(size_t)i + 1] - x[(size_t)i], hl = x[(size_t)i] - x[(size_t)i - 1];
-                b[(size_t)i] = -h / (hl * (hl + h)) * y[(size_t)i - 1] + (h - hl) / (hl * h) * y[(size_t)i] + hl / (h * (hl + h)) * y[(size_t)i + 1];
-            }
-            b[0] = 0.5 * (-b[1] + 3.0 * (y[1] - y[0]) / (x[1] - x[0]));
-            b[(size_t)n - 1] = 0.5 * (-b[(size_t)n - 2] + 3.0 * (y[(size_t)n - 1] - y[(size_t)n - 2]) / (x[(size_t)n - 1] - x[(size_t)n - 2]));
-            for (int i = 0; i < n - 1; i++) {
-                const double h = x[(size_t)i + 1] - x[(size_t)i];
-                c[(size_t)i] = (3.0 * (y[(size_t)i + 1] - y[(size_t)i]) / h - (2.0 * b[(size_t)i] + b[(size_t)i + 1])) / h;
-                d[(size_t)i] = ((b[(size_t)i + 1] - b[(size_t)i]) / (3.0 * h) - 2.0 / 3.0 * c[(size_t)i]) / h;
-            }
-        }
-        c0 = c[0];
-        return true;
-    }
-    double operator()(double v) const {
-        const size_t n = x.size();
-        size_t idx = 0;
-        while (idx + 1 < n && x[idx + 1] <= v) idx++;
-        const double h = v - x[idx];
-        if (v < x[0]) return (c0 * h + b[0]) * h + y[0];
-        if (v > x[n - 1]) return (c[n - 1] * h + b[n - 1]) * h + y[n - 1];
-        return ((d[idx] * h + c[idx]) * h + b[idx]) * h + y[idx];
-    }
-};
-
-struct Unpacked {  // host scalars of one vector
-    int Nmax, lmax, Nfl0, Nfl1, Nfl2, Nfl3, Nnoise, onoise, ocfg, os, o1;
-    bool do_amp;
-    double g[6], trunc_c, model_type, bias_type, Hfactor, Wfactor, rot_env, rot_core, inclination, Vl[4], eta0, asym;
-    int Nferr;
-    std::vector<double> Wl0, Hl0;
-    double fmin, fmax;
-};
-
-double app_width(const double g[6], double f) {  // models.cpp:4788-4794
-    const double lnGamma0 = g[2] * std::log(f / g[0]) + std::log(g[3]);
-    const double e = 2. * std::log(f / g[1]) / std::log(g[4] / g[0]);
-    return std::exp(lnGamma0 + -std::log(g[5]) / (1. + std::pow(e, 2)));
-}
-
-// models.cpp:4727-4866 (id 25) / :4377-4470 (id 27, cte_width: one width parameter, Wl0 constant, :4407) + solver_mm.cpp:470-555 /
-// :624-705 (everything before the pair loop)
-int unpack(const double *p, const int32_t *pl, double step, bool cte_width, Unpacked &u, Prep &P) {
-    const long double pi = M_PI;
-    std::memset(&P, 0, sizeof P);
-    u.Nmax = pl[0]; u.lmax = pl[1]; u.Nfl0 = pl[2]; u.Nfl1 = pl[3]; u.Nfl2 = pl[4]; u.Nfl3 = pl[5];
-    const int Nsplit = pl[6], Nwidth = pl[7], Ninc = pl[9];
-    u.Nnoise = pl[8];
-    const int Nf = u.Nfl0 + u.Nfl1 + u.Nfl2 + u.Nfl3;
-    u.os = u.Nmax + u.lmax + Nf;
-    u.onoise = u.os + Nsplit + Nwidth;
-    u.ocfg = u.onoise + u.Nnoise + Ninc;
-    u.o1 = u.Nmax + u.lmax + u.Nfl0;
-    u.trunc_c = p[u.ocfg];
-    u.do_amp = p[u.ocfg + 1] != 0;
-    u.model_type = p[u.ocfg + 3];
-    u.bias_type = p[u.ocfg + 4];
-    u.Nferr = (int)p[u.ocfg + 5];
-    if (u.Nmax < 2 || u.Nmax != u.Nfl0 || u.Nferr < 0 || u.Nfl1 != 8 + 2 * u.Nferr || Nwidth < (cte_width ? 1 : 6) || Nsplit < 10 || u.lmax > 3)
-        return TAMCMC_ERR_BAD_ARG;
-    for (int k = 0; k < 6; k++) u.g[k] = k < (cte_width ? 1 : 6) ? std::fabs(p[u.os + Nsplit + k]) : 0.0;
-    const double *fl0 = p + u.Nmax + u.lmax;
-    u.Wl0.resize((size_t)u.Nmax); u.Hl0.resize((size_t)u.Nmax);
-    for (int n = 0; n < u.Nmax; n++) u.Wl0[(size_t)n] = cte_width ? u.g[0] : app_width(u.g, fl0[n]);
-    for (int n = 0; n < u.Nmax; n++)
-        u.Hl0[(size_t)n] = u.do_amp ? (double)fabsl(p[n] * (1. / u.Wl0[(size_t)n] / pi)) : std::fabs(p[n]);
-    const double delta0l = p[u.o1], DPl = std::fabs(p[u.o1 + 1]), alpha_g = std::fabs(p[u.o1 + 2]), q = std::fabs(p[u.o1 + 3]);
-    u.Wfactor = std::fabs(p[u.o1 + 6]); u.Hfactor = std::fabs(p[u.o1 + 7]);
-    u.rot_env = std::fabs(p[u.os]); u.rot_core = std::fabs(p[u.os + 1]);
-    u.asym = p[u.os + 9];
-    u.inclination = std::fabs(p[u.onoise + u.Nnoise]);
-    u.Vl[0] = 1;
-    for (int l = 1; l <= 3; l++) u.Vl[l] = l <= u.lmax ? std::fabs(p[u.Nmax + l - 1]) : 0.0;
-    u.eta0 = (p[u.os + 8] == 1) ? mt::eta0_fct(fl0, u.Nfl0) : 0.0;
-    u.fmin = *std::min_element(fl0, fl0 + u.Nfl0);
-    u.fmax = *std::max_element(fl0, fl0 + u.Nfl0);
-    double fit[2];
-    mt::linfit_index(fl0, u.Nfl0, fit);
-    const double Dnu_p = fit[0];
-    // the reference exits (models.cpp:4851-4857; id 27 only tests it for model_type 0, :4459, and would otherwise hand its solver a zero
-    // lower bound, i.e. an unbounded g-mode count: refused here too)
-    if (!(Dnu_p > 0) || u.fmin - Dnu_p < 0) return TAMCMC_ERR_BAD_ARG;
-    P.Dnu_p = Dnu_p; P.DPl = DPl; P.alpha = alpha_g; P.q = q; P.resol = step; P.fact = 0.04;
-    double fmin_s, fmax_s;
-    if (u.model_type == 0) {  // solve_mm_asymptotic_O2p(Dnu_p, eps, 1, delta0l, 0, 0, ...), fmin - Dnu .. fmax + Dnu
-        const int n0 = (int)std::floor(fit[1] / Dnu_p);
-        const double eps = fit[1] / Dnu_p - n0;
-        fmin_s = u.fmin - Dnu_p; fmax_s = u.fmax + Dnu_p;
-        const int el = 1;
-        int np_min = (int)std::floor(fmin_s / Dnu_p - eps - el / 2 - delta0l);  // el/2: integer division, as in the reference
-        int np_max = (int)std::ceil(fmax_s / Dnu_p - eps - el / 2 - delta0l);
-        int ng_min = (int)std::floor(1e6 / (fmax_s * DPl) - alpha_g), ng_max = (int)std::ceil(1e6 / (fmin_s * DPl) - alpha_g);
-        if (ng_min <= 0 && ng_max < 1) { P.Lp = 0; return TAMCMC_OK; }  // "impossible star": no mixed modes, the model carries on (solver_mm.cpp:497-501)
-        if (ng_min <= 0 && ng_max >= 1) ng_min = 1;
-        P.zone = (ng_max - ng_min < 6) ? (double)np_max : 1.75;
-        if (np_min <= 0) np_min = 1;
-        P.Lp = np_max - np_min; P.Lg = ng_max - ng_min; P.ng_min = ng_min;
-        if (P.Lg < 1) { P.Lp = 0; return TAMCMC_OK; }  // no g mode in range
-        if (P.Lp < 1 || P.Lp > MAXP) return TAMCMC_ERR_BAD_ARG;
-        for (int np = np_min; np < np_max; np++) {
-            P.nu_p[np - np_min] = (double)((np + (long double)eps + el / 2.L + delta0l) * Dnu_p);
-            P.dnu_loc[np - np_min] = Dnu_p;  // alpha_p = 0
-        }
-        P.keep_lo = fmin_s; P.keep_hi = fmax_s;
-    } else {  // solve_mm_asymptotic_O2from_l0(fl0, 1, delta0l, ...): the l=0 ladder shifted, three extra orders on each side
-        fmin_s = u.fmin - Dnu_p; fmax_s = u.fmax + Dnu_p;
-        if (fmin_s < 0) fmin_s = 0;
-        int ng_min = (int)std::floor(1e6 / (fmax_s * DPl) - alpha_g), ng_max = (int)std::ceil(1e6 / (fmin_s * DPl) - alpha_g);
-        if (ng_min <= 0 && ng_max < 1) { P.Lp = 0; return TAMCMC_OK; }
-        if (ng_min <= 0 && ng_max >= 1) ng_min = 1;
-        P.zone = (ng_max - ng_min < 6) ? 20. : 1.75;
-        std::vector<double> ext;
-        ext.push_back(u.fmin - 3 * Dnu_p); ext.push_back(u.fmin - 2 * Dnu_p); ext.push_back(u.fmin - Dnu_p);
-        for (int k = 0; k < u.Nfl0; k++) ext.push_back(fl0[k]);
-        ext.push_back(u.fmax + Dnu_p); ext.push_back(u.fmax + 2 * Dnu_p); ext.push_back(u.fmax + 3 * Dnu_p);
-        int Lp = 0;
-        for (double e : ext) {
-            const double v = e + (double)(1 / 2.L * Dnu_p + delta0l);
-            if (v >= fmin_s && v <= fmax_s) {
-                if (Lp >= MAXP) return TAMCMC_ERR_BAD_ARG;
-                P.nu_p[Lp++] = v;
-            }
-        }
-        P.Lp = Lp; P.Lg = ng_max - ng_min; P.ng_min = ng_min;
-        if (P.Lg < 1) { P.Lp = 0; return TAMCMC_OK; }
-        if (P.Lp < 2) return TAMCMC_ERR_BAD_ARG;
-        P.keep_lo = u.fmin; P.keep_hi = u.fmax;
-    }
-    if (fmin_s <= 150) P.fact = 0.01;
-    if (fmin_s <= 50) P.fact = 0.005;
-    // first derivative of the p ladder on the index grid (derivatives_handler.cpp:425-457)
-    for (int i = 0; i < P.Lp; i++) {
-        if (P.Lp == 1) P.dnup[i] = 0;
-        else if (i == 0) P.dnup[i] = P.nu_p[1] - P.nu_p[0];
-        else if (i == P.Lp - 1) P.dnup[i] = P.nu_p[i] - P.nu_p[i - 1];
-        else P.dnup[i] = (P.nu_p[i + 1] - P.nu_p[i - 1]) / 2.;
-    }
-    if (u.model_type != 0)
-        for (int i = 0; i < P.Lp; i++) P.dnu_loc[i] = P.dnup[i];  // the from-l0 driver hands the local derivative to the solver (:717)
-    for (int ip = 0; ip < P.Lp; ip++) {
-        P.ig0[ip] = -1;
-        const double lo = P.nu_p[ip] - P.zone * Dnu_p, hi = P.nu_p[ip] + P.zone * Dnu_p;
-        for (int ig = 0; ig < P.Lg; ig++) {
-            const double g = nu_g_of(P, ig);
-            if (g >= lo && g <= hi) { P.ig0[ip] = ig; break; }
-        }
-    }
-    return TAMCMC_OK;
 }
 
 }  // namespace
@@ -644,7 +527,6 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     const int stride = plength[8] > 0 ? plength[8] : 1;
     if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
     if (plength[2] > MAXL || plength[4] > MAXL || plength[5] > MAXL) return TAMCMC_ERR_BAD_ARG;
-    std::vector<Unpacked> U((size_t)B);
     // Prep and RowIn arrays are filled in ONE pinned block (a single asynchronous upload); the per-vector status words come back
     // into the same block and are read by rgb_collect_status after the caller's final synchronisation
     const size_t bytes_prep = ((size_t)B * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)B * sizeof(RowIn) + 15) & ~(size_t)15;
@@ -658,56 +540,18 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     unsigned char *h = c->h_stage.p;
     int32_t *h_nh = (int32_t *)(h + L.off_nh), *h_nn = (int32_t *)(h + L.off_nn);
     double *h_noise = (double *)(h + L.off_noise);
+    std::vector<double> fmins((size_t)B, 1e300);
     int nthr = omp_get_max_threads();  // the scalar unpack of a vector (width law, fits, spline coefficients) is independent of the others
     if (nthr > 8) nthr = 8;
     if (nthr > B / 4) nthr = B / 4 > 0 ? B / 4 : 1;
 #pragma omp parallel for schedule(static) num_threads(nthr)
-    for (int b = 0; b < B; b++) {
-        const double *p = params + (size_t)b * Nparams;
-        Unpacked &u = U[(size_t)b];
-        RowIn &ri = R[b];
-        std::memset(&ri, 0, sizeof ri);
-        int st = unpack(p, plength, step, cte_width, u, P[b]);
-        if (st == TAMCMC_OK && u.bias_type != 0) {
-            Spline s;
-            if (u.Nferr > MAXNODE || !s.set(p + u.o1 + 8, p + u.o1 + 8 + u.Nferr, u.Nferr, u.bias_type == 1 ? 1 : 2)) st = TAMCMC_ERR_BAD_ARG;
-            else {
-                ri.bias_n = u.Nferr;
-                for (int i = 0; i < u.Nferr; i++) {
-                    ri.sx[i] = s.x[(size_t)i]; ri.sy[i] = s.y[(size_t)i]; ri.sb[i] = s.b[(size_t)i]; ri.sc[i] = s.c[(size_t)i]; ri.sd[i] = s.d[(size_t)i];
-                }
-                ri.sc0 = s.c0;
-            }
-        }
-        status[b] = st;
-        P[b].status = st;
-        P[b].probe_dense = dense_scan ? 1 : 0;
-        ri.status = st;
-        if (st == TAMCMC_OK) {
-            ri.Nfl0 = u.Nfl0; ri.Nfl2 = u.Nfl2; ri.Nfl3 = u.Nfl3; ri.lmax = u.lmax; ri.do_amp = u.do_amp ? 1 : 0; ri.cte_width = cte_width ? 1 : 0;
-            const double *fl0 = p + u.Nmax + u.lmax;
-            for (int k = 0; k < u.Nfl0; k++) { ri.fl0[k] = fl0[k]; ri.Wl0[k] = u.Wl0[(size_t)k]; ri.Hl0[k] = u.Hl0[(size_t)k]; }
-            for (int k = 0; k < u.Nfl2; k++) ri.fl2[k] = std::fabs(p[u.o1 + u.Nfl1 + k]);
-            for (int k = 0; k < u.Nfl3; k++) ri.fl3[k] = std::fabs(p[u.o1 + u.Nfl1 + u.Nfl2 + k]);
-            for (int k = 0; k < 6; k++) ri.g[k] = u.g[k];
-            for (int l = 0; l < 4; l++) ri.Vl[l] = u.Vl[l];
-            ri.V[0][0] = 1.0;
-            for (int l = 1; l <= u.lmax; l++) mt::amplitude_ratio(l, u.inclination, ri.V[l]);
-            ri.eta0 = u.eta0; ri.asym = u.asym; ri.trunc_c = u.trunc_c; ri.Hfactor = u.Hfactor; ri.Wfactor = u.Wfactor;
-            ri.rot_env = u.rot_env; ri.rot_core = u.rot_core;
-            ri.a2 = p[u.os + 2]; ri.a3 = p[u.os + 4]; ri.a4 = p[u.os + 5]; ri.a5 = p[u.os + 6]; ri.a6 = p[u.os + 7];
-            ri.fmin = u.fmin; ri.fmax = u.fmax;
-            for (int k = 0; k < u.Nnoise; k++) h_noise[(size_t)b * stride + k] = std::fabs(p[u.onoise + k]);
-            h_nh[b] = (u.Nnoise - 1) / 3; h_nn[b] = u.Nnoise;
-        } else {
-            h_noise[(size_t)b * stride] = 1.0;  // placeholder row; logL[b] is overwritten with NaN
-            h_nh[b] = 0; h_nn[b] = 1;
-        }
-    }
+    for (int b = 0; b < B; b++)
+        status[b] = unpack_vector(OneThread(), params + (size_t)b * Nparams, plength, step, cte_width, dense_scan ? 1 : 0, P[b], R[b], h_noise + (size_t)b * stride,
+                                  h_nh + b, h_nn + b, &fmins[(size_t)b]);
     double fmin_all = 1e300;
     *first_err = TAMCMC_OK;
     for (int b = 0; b < B; b++) {
-        if (status[b] == TAMCMC_OK && U[(size_t)b].fmin < fmin_all) fmin_all = U[(size_t)b].fmin;
+        if (status[b] == TAMCMC_OK && fmins[(size_t)b] < fmin_all) fmin_all = fmins[(size_t)b];
         if (status[b] != TAMCMC_OK && *first_err == TAMCMC_OK) *first_err = status[b];
     }
     hipStream_t st = c->stream;
@@ -729,12 +573,9 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage.p, L.off_mults, hipMemcpyHostToDevice, st));  // header only
     HIPCHK(c, hipMemcpyAsync(d_prep, P, bytes_prep + bytes_rows, hipMemcpyHostToDevice, st));  // Prep and RowIn arrays, contiguous on both sides
     HIPCHK(c, hipMemsetAsync(d_norm, 0, (size_t)B * (sizeof(unsigned long long) + 2 * sizeof(int)), st));
-    hipLaunchKernelGGL(k_armm_scan, dim3(MAXP, B), dim3(64), 0, st, d_prep, d_sols, d_nsol);
-    hipLaunchKernelGGL(k_armm_sort_unique, dim3(B), dim3(WG), 0, st, d_prep, d_rows, d_sols, d_nsol, d_fl1);
-    const int chunks = 24;
-    hipLaunchKernelGGL(k_zeta, dim3(chunks, B), dim3(WG), 0, st, d_prep, d_fl1, d_nsol, d_ksi, d_norm, chunks);
-    hipLaunchKernelGGL(k_rgb_rows, dim3(B), dim3(WG), 0, st, d_prep, d_rows, (const mt::PolyTab *)c->d_poly.p, d_fl1, d_nsol, d_ksi, d_norm, hx[0],
-                       hx[Nx - 1], (long)Nx, step, per, (tamcmc_multiplet *)(c->d_stage.p + L.off_mults), (int *)(c->d_stage.p + L.off_pairs), d_status);
+    hipLaunchKernelGGL(k_armm_solve, dim3(MAXP + ZCHUNKS, B), dim3(SOLVE_NT), 0, st, d_prep, d_sols, d_nsol, d_norm);
+    hipLaunchKernelGGL(k_rgb_finish, dim3(B), dim3(WG), 0, st, d_prep, d_rows, (const mt::PolyTab *)c->d_poly.p, d_sols, d_nsol, d_fl1, d_ksi, d_norm, hx[0],
+                       hx[Nx - 1], (long)Nx, step, per, 0, (tamcmc_multiplet *)(c->d_stage.p + L.off_mults), (int *)(c->d_stage.p + L.off_pairs), d_status, BgOut());
     HIPCHK(c, hipGetLastError());
     // the device-side status words (row builder, solver overflow) travel back behind the kernels; no synchronisation here: the
     // likelihood launch that follows runs on whatever rows were written (a failed vector has an empty range) and the caller reads
@@ -745,6 +586,66 @@ int rgb_stage_params(tamcmc_hip_ctx *c, int model_id, int B, const double *param
     const int tb = tile_bins(c->wgs, c->K), ntiles = (int)((Nx + tb - 1) / tb);
     double t = (fmin_all < 1e299) ? (fmin_all - hx[0]) / (hx[1] - hx[0]) / (double)tb - 3.0 : 0.0;  // first near-field tile: a little below the lowest radial mode
     *tile_rot_out = (t > 0 && t < ntiles) ? (int)t : 0;
+    return TAMCMC_OK;
+}
+
+// Device engine (dev_sampler.hip): the same pre-step on parameter vectors that are ALREADY in device memory -- nothing crosses PCIe and
+// nothing is synchronised.  rgb_device_prepare() sizes the workspace once (outside the iteration loop); the sampler's proposal kernel
+// runs the scalar unpack itself (rgb_unpack.h) into the slice rgb_device_slice() describes; rgb_device_stage() enqueues the solver and
+// the sort / zeta / row kernel on `st`, writing the tables into the engine's own likelihood input block T.
+static size_t rgb_slice_bytes(int B) {
+    using namespace rgb;
+    const size_t bytes_prep = ((size_t)B * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)B * sizeof(RowIn) + 15) & ~(size_t)15;
+    return (bytes_prep + bytes_rows + (size_t)B * MAXSOL * 3 * sizeof(double) + (size_t)B * (3 * sizeof(int) + sizeof(unsigned long long)) + 255) & ~(size_t)255;
+}
+
+int rgb_device_prepare(tamcmc_hip_ctx *c, int Bmax, int slices, const int32_t *plength, int *per_out, int *stride_out) {
+    using namespace rgb;
+    const int stride = plength[8] > 0 ? plength[8] : 1;
+    if ((stride - 1) / 3 > TAMCMC_MAX_HARVEY) return TAMCMC_ERR_BAD_ARG;
+    if (plength[2] > MAXL || plength[4] > MAXL || plength[5] > MAXL || plength[2] < 2) return TAMCMC_ERR_BAD_ARG;
+    HIPCHK(c, c->d_rgb.reserve(rgb_slice_bytes(Bmax) * (size_t)slices));
+    if (!c->poly_ready) {
+        HIPCHK(c, c->d_poly.reserve(sizeof(mt::PolyTab)));
+        hipLaunchKernelGGL(k_fill_poly_rgb, dim3(1), dim3(64), 0, c->stream, (mt::PolyTab *)c->d_poly.p);
+        c->poly_ready = true;
+    }
+    *per_out = plength[2] + plength[4] + plength[5] + CAP1;
+    *stride_out = stride;
+    return TAMCMC_OK;
+}
+
+rgb::Slice rgb_device_slice(tamcmc_hip_ctx *c, int Bmax, int slice) {
+    using namespace rgb;
+    const size_t bytes_prep = ((size_t)Bmax * sizeof(Prep) + 15) & ~(size_t)15, bytes_rows = ((size_t)Bmax * sizeof(RowIn) + 15) & ~(size_t)15;
+    const size_t nsolbuf = (size_t)Bmax * MAXSOL;
+    unsigned char *base = c->d_rgb.p + rgb_slice_bytes(Bmax) * (size_t)slice;
+    Slice S;
+    S.preps = (Prep *)base;
+    S.rows = (RowIn *)(base + bytes_prep);
+    S.norm_bits = (unsigned long long *)((double *)(base + bytes_prep + bytes_rows) + 3 * nsolbuf);
+    S.nsol = (int *)(S.norm_bits + Bmax);
+    S.step = c->hx[2] - c->hx[1];
+    S.dense = c->armm_dense ? 1 : 0;
+    return S;
+}
+
+int rgb_device_stage(tamcmc_hip_ctx *c, int b0, int B, int Bmax, int slice, int per, const RgbDeviceTables &T, hipStream_t st) {
+    using namespace rgb;
+    const double *hx = c->hx.data();
+    const int64_t Nx = c->Nx;
+    const double step = hx[2] - hx[1];  // models.cpp:4719
+    const Slice S = rgb_device_slice(c, Bmax, slice);
+    double *d_sols = (double *)((unsigned char *)S.rows + (((size_t)Bmax * sizeof(RowIn) + 15) & ~(size_t)15));
+    const size_t nsolbuf = (size_t)Bmax * MAXSOL;
+    double *d_fl1 = d_sols + nsolbuf, *d_ksi = d_fl1 + nsolbuf;
+    hipLaunchKernelGGL(k_armm_solve, dim3(MAXP + ZCHUNKS, B), dim3(SOLVE_NT), 0, st, S.preps, d_sols, S.nsol, S.norm_bits);
+    BgOut bg;
+    bg.out = T.bg; bg.noise = T.noise; bg.stride = T.stride; bg.nh = T.nh; bg.nn = T.nn; bg.ntiles = T.ntiles; bg.tile_bins = T.tile_bins;
+    bg.x0 = hx[0]; bg.step = hx[1] - hx[0];
+    hipLaunchKernelGGL(k_rgb_finish, dim3(B), dim3(WG), 0, st, S.preps, S.rows, (const mt::PolyTab *)c->d_poly.p, d_sols, S.nsol, d_fl1, d_ksi, S.norm_bits, hx[0],
+                       hx[Nx - 1], (long)Nx, step, per, b0, T.mults, T.pairs, T.status, bg);
+    HIPCHK(c, hipGetLastError());
     return TAMCMC_OK;
 }
 

@@ -89,16 +89,18 @@ def test_c5_forty_vector_batch_at_2e5_bins(pkg, oracle, synth):
     ctx.close()
 
 
-def test_c5_forty_chain_sampler_run(pkg, synth):
-    """40 tempered chains (the reference caps Nchains at 24, MALA.cpp:580-587) on the 2e5-bin red giant, host-driven engine with the
-    solver on the device: finite statistics, chains move, swaps happen, adaptation keeps the covariance matrices symmetric."""
+@pytest.mark.parametrize("engine", ["host", "device"])
+def test_c5_forty_chain_sampler_run(pkg, synth, engine):
+    """40 tempered chains (the reference caps Nchains at 24, MALA.cpp:580-587) on the 2e5-bin red giant, the solver on the device.
+    host: one batched call per iteration; device: the whole iteration enqueued (proposal + unpack, solver, rows, likelihood per chain
+    group, four groups).  Finite statistics, chains move, swaps happen, adaptation keeps the covariance matrices symmetric."""
     rs = synth.make_c5_star(nx=200000, nmax=10, dnu=10.0, bias_type=1, nferr=6)
     ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
     ctx.set_spectrum(rs.x, np.ones_like(rs.x))
     _, mr, _ = ctx.loglike_params_batch(rs.model_id, rs.params, rs.plength, want_model=True)
     rs.set_spectrum_from_model(mr[0], 7)
     ctx.set_spectrum(rs.x, rs.y)
-    s = pkg.Sampler(ctx, rs, nchains=40, lambda_temp=1.15, seed=5, engine="host", Nt_learn=(10, 120), periods_learn=(1,))
+    s = pkg.Sampler(ctx, rs, nchains=40, lambda_temp=1.15, seed=5, engine=engine, Nt_learn=(10, 120), periods_learn=(1,))
     smp, st = s.run(200, stats=True)
     state = s.state()
     assert smp.shape == (200, 40, rs.nvars) and np.all(np.isfinite(st[:, :, 0])) and state["iteration"] == 200
@@ -106,6 +108,11 @@ def test_c5_forty_chain_sampler_run(pkg, synth):
     assert np.mean(np.any(smp[1:] != smp[:-1], axis=2)) > 0.05
     mu, cov = s.get_proposal(0)
     assert np.allclose(cov, cov.T, rtol=1e-12, atol=1e-300) and np.all(np.diag(cov) > 0)
+    if engine == "device":          # the chain groups are a launch arrangement only: same chains with one group
+        s1 = pkg.Sampler(ctx, rs, nchains=40, lambda_temp=1.15, seed=5, engine="device", Nt_learn=(10, 120), periods_learn=(1,), chain_groups=1)
+        smp1, st1 = s1.run(200, stats=True)
+        assert np.array_equal(smp1, smp) and np.array_equal(st1, st)
+        s1.close()
     s.close(); ctx.close()
 
 

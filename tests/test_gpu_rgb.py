@@ -1,6 +1,6 @@
 """Red-giant model (id 25, BASELINE config C5 family) on the device: the ARMM mixed-mode solver and the zeta function run as HIP
 kernels (csrc/rgb_prestep.hip), the variable-length table goes through the same k_loglike as the main-sequence models.
-Checked against the oracle's restatement (oracle/armm_oracle.c; parity unpinned by the reference, see that file)."""
+Checked against the oracle's restatement (oracle/armm_oracle.c, pinned on the reference's own solver outputs: tests/test_armm_scanner_fixtures.py)."""
 import numpy as np
 import pytest
 
@@ -63,8 +63,7 @@ def test_rgb_bad_vectors_are_reported_not_guessed(pkg, oracle, synth):
 @pytest.mark.parametrize("cte", [False, True])
 def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth, cte):
     """Red-giant star end to end: priors (io_asymptotic) on the host, ONE batched device call per iteration whose tables come from
-    the device pre-step, adaptive MH + parallel tempering (host-driven engine; the device-resident engine does not carry the
-    pre-step yet and must refuse the model)."""
+    the device pre-step, adaptive MH + parallel tempering (host-driven engine)."""
     star = synth.make_c5_star(nx=6000, nmax=6, nferr=4, cte_width=cte)
     st, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
     assert st == 0
@@ -81,9 +80,66 @@ def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth, cte):
     assert (smp[:, 0] != smp[0, 0]).any() and s.state()["swap_attempts"] == 149
     assert stat[-50:, 0, 2].mean() > st0["logPost"][0] - 30.0
     s.close()
-    with pytest.raises(pkg.TamcmcError):
-        pkg.Sampler(ctx, star, nchains=4, engine="device")
     ctx.close()
+
+
+@pytest.mark.parametrize("cte,learn", [(False, None), (True, None), (False, (15, 70))])
+def test_rgb_device_engine_follows_the_host_engine(pkg, oracle, synth, cte, learn):
+    """Red-giant star on the device-resident engine: proposal and log-prior in k_iterate, then the pre-step (scalar unpack, mixed-mode
+    solver, zeta, rows) on the proposals where they lie in device memory, likelihood, MH test / swap / adaptation in the next k_iterate:
+    no host round trip per iteration.  Same random streams as the host-driven engine (which evaluates prior and scalar unpack in long
+    double like the reference, the device in double): the trajectories agree to rounding until a knife-edge decision."""
+    star = synth.make_c5_star(nx=6000, nmax=6, nferr=4, cte_width=cte)
+    st, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+    assert st == 0
+    star.set_spectrum_from_model(m0, 4)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, star.y)
+    kw = dict(nchains=5, lambda_temp=1.5, seed=21, Nt_learn=learn or (10**9, 10**9 + 1), periods_learn=(1,), dN_mixing=1)
+    h = pkg.Sampler(ctx, star, engine="host", **kw)
+    d = pkg.Sampler(ctx, star, engine="device", **kw)
+    n = 100
+    sh, th = h.run(n, stats=True)
+    sd, td = d.run(60, stats=True)
+    sd2, td2 = d.run(n - 60, stats=True)                     # a second call continues the chain
+    sd, td = np.concatenate([sd, sd2]), np.concatenate([td, td2])
+    same = np.all(np.isclose(sh, sd, rtol=1e-8, atol=1e-11), axis=(1, 2))
+    first_div = n if same.all() else int(np.argmin(same))
+    assert first_div >= 40, f"engines diverge at iteration {first_div}"
+    assert np.allclose(th[:first_div], td[:first_div], rtol=1e-7, atol=1e-6)
+    a, b = h.state(), d.state()
+    assert a["iteration"] == b["iteration"] == n and a["swap_attempts"] == b["swap_attempts"] == n - 1
+    assert np.isfinite(td).all() and (sd[:, 0] != sd[0, 0]).any()
+    # what the engine holds for each chain is the likelihood of the position it holds (oracle, red-giant tolerance)
+    T = 1.5 ** np.arange(5)
+    held = np.tile(star.params, (5, 1))
+    held[:, star.index_to_relax] = b["vars"]
+    ref, _, so = oracle.loglike_batch(star.model_id, held, star.plength, star.x, star.y, 1.0, T)
+    assert (so == 0).all() and np.allclose(b["logL"], ref, rtol=1e-7)
+    h.close(); d.close(); ctx.close()
+
+
+def test_rgb_device_engine_rejects_vectors_the_prestep_refuses(pkg, oracle, synth):
+    """A chain started where proposals often leave the prior or break the l=0 ladder: such proposals are rejected (never accepted with
+    a table that was not built), the chain stays finite."""
+    from tamcmc_c_amd.sampler import default_errors
+    star = synth.make_c5_star(nx=6000, nmax=6, nferr=4)
+    st, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+    star.set_spectrum_from_model(m0, 4)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, star.y)
+    d = pkg.Sampler(ctx, star, nchains=3, lambda_temp=2.0, seed=2, engine="device", Nt_learn=(10**9, 10**9 + 1), periods_learn=(1,),
+                    init_errors=400.0 * default_errors(star))
+    smp, stat = d.run(80, stats=True)
+    assert np.isfinite(stat).all() and np.isfinite(smp).all()
+    moved = np.any(smp[1:] != smp[:-1], axis=2)
+    assert moved.mean() < 0.5                                 # most of these wild proposals are refused
+    stt = d.state()
+    held = np.tile(star.params, (3, 1))
+    held[:, star.index_to_relax] = stt["vars"]
+    ref, _, so = oracle.loglike_batch(star.model_id, held, star.plength, star.x, star.y, 1.0, 2.0 ** np.arange(3))
+    assert (so == 0).all() and np.allclose(stt["logL"], ref, rtol=1e-7)
+    d.close(); ctx.close()
 
 
 def test_structured_scan_finds_the_cells_of_the_dense_walk(pkg, synth):
