@@ -162,6 +162,14 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
         }
     }
 #endif
+#ifdef TAMCMC_PROBE  // phase stamps of the middle tile of evaluation 0 (wall_clock64: 100 MHz), printed after the launch
+    static long *probe_dbg = nullptr;
+    if (getenv("TAMCMC_PROBE_STAMPS")) {
+        if (!probe_dbg) (void)hipMalloc((void **)&probe_dbg, 16 * sizeof(long));
+        (void)hipMemsetAsync(probe_dbg, 0, 16 * sizeof(long), st);
+        a.dbg = probe_dbg;
+    }
+#endif
     if (device_tables) a.tile_rot = tile_rot;
     else {
         const int32_t *pairs = (const int32_t *)(c->h_stage.p + L.off_pairs);
@@ -181,6 +189,14 @@ static int run_staged(tamcmc_hip_ctx *c, int B, const StageLayout &L, int noise_
     if (model)
         HIPCHK(c, hipMemcpyAsync(model, c->d_model.p, (size_t)B * Nx * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+#ifdef TAMCMC_PROBE
+    if (a.dbg) {
+        long h[16];
+        (void)hipMemcpy(h, a.dbg, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "tile stamps (us since entry): setup %.2f | staged %.2f | near %.2f | far coef %.2f | poly %.2f | reduced+stored %.2f\n", (h[1] - h[0]) * 0.01,
+                (h[2] - h[0]) * 0.01, (h[3] - h[0]) * 0.01, (h[4] - h[0]) * 0.01, (h[5] - h[0]) * 0.01, (h[6] - h[0]) * 0.01);
+    }
+#endif
     if (c->timing) {
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));

@@ -346,16 +346,32 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
             g = a.mults[min(idx, mend - 1)];  // the whole row in ONE round trip (clamped index: lanes past the end stage nothing)
             const int i0 = g.i0, i1 = g.i1;
             const bool ov = (idx < mend) && (i0 < t1) && (i1 > t0) && !PROBE_SKIP(16);
-            const unsigned long long mask = __ballot(ov);
+            // every overlapping multiplet is staged with its per-multiplet scalars hoisted: the NEAR ones first (in table order: the
+            // per-bin loop below walks them without looking at a flag), the far ones -- they only feed the tile polynomial -- behind
+            // them.  Pass 1 decides near / far (its temporaries die at the ballot), pass 2 builds the LDS image in place.
+            const int l = g.l;
+            const int nm = 2 * l + 1;
+            const bool full = (i0 <= t0 && i1 >= t1);
             bool far = false;
+            if (FARFIELD && ov && full) {
+                const double ig = 2.0 * rcp_nr2(g.gamma);
+                const double beta2 = (ig * h) * (ig * h);
+                const double r2 = (g.asym != 0.0) ? RHO_MAX2_ASYM : RHO_MAX2;
+                far = true;
+#pragma unroll
+                for (int m = 0; m < 7; m++) {
+                    const double A = ig * (g.nu[m] - xc);
+                    if (m < nm && !(beta2 <= r2 * fma(A, A, 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
+                }
+            }
+            const unsigned long long mask = __ballot(ov);
+            const unsigned long long fmask = FARFIELD ? __ballot(far) : 0ull;
+            const unsigned long long lt = (1ull << tid) - 1ull;
+            const int n_near = __popcll(mask & ~fmask);
+            const int pos = far ? n_near + __popcll(fmask & lt) : __popcll(mask & ~fmask & lt);
             if (ov) {
-                // every overlapping multiplet is staged (in order) with its per-multiplet scalars hoisted; far ones are flagged
-                const int pos = __popcll(mask & ((1ull << tid) - 1ull));
                 LdsMult &d = s_m[pos];
-                const int l = g.l;
-                const int nm = 2 * l + 1;
                 int flags = 0;
-                const bool full = (i0 <= t0 && i1 >= t1);
                 if (full) flags |= F_FULL;
                 if (g.asym != 0.0) flags |= F_ASYM;
                 // FAST: reciprocal + Newton steps instead of the two IEEE divides by nu_c (exact zeros when asym = 0 either way)
@@ -370,14 +386,6 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
                     d.fcx = g.asym * ifc;
 #pragma unroll
                     for (int m = 0; m < 7; m++) Am[m] = ig * (g.nu[m] - xc);  // constant trip count: g stays in registers
-                    if (FARFIELD && full) {
-                        const double beta2 = (ig * h) * (ig * h);
-                        const double r2 = (g.asym != 0.0) ? RHO_MAX2_ASYM : RHO_MAX2;
-                        far = true;
-#pragma unroll
-                        for (int m = 0; m < 7; m++)
-                            if (m < nm && !(beta2 <= r2 * fma(Am[m], Am[m], 1.0))) far = false;  // rho^2 = beta^2/(A^2+1); also rejects NaN
-                    }
                     if (far) flags |= F_FAR;
                     else {
                         // prod_m (1 + ((x-nu_m) ig)^2) < (1e38)^7 = 1e266 on the whole tile?
@@ -401,28 +409,25 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
             if (FARFIELD) {
                 // far components packed densely (no idle lanes for l < 3): offset = components of the far multiplets before this lane
                 const int lv = ov ? g.l : 0;
-                const unsigned long long lt = (1ull << tid) - 1ull;
                 const unsigned long long f0 = __ballot(far && lv == 0), f1 = __ballot(far && lv == 1), f2 = __ballot(far && lv == 2),
                                          f3 = __ballot(far && lv >= 3);
                 if (far) {
                     const int off = __popcll(f0 & lt) + 3 * __popcll(f1 & lt) + 5 * __popcll(f2 & lt) + 7 * __popcll(f3 & lt);
-                    const int pos = __popcll(mask & lt);
-                    const int nm = 2 * (lv > 3 ? 3 : lv) + 1;
-                    for (int m = 0; m < nm; m++) s_slot[off + m] = (unsigned short)((pos << 3) | m);
+                    const int nmf = 2 * (lv > 3 ? 3 : lv) + 1;
+                    for (int m = 0; m < nmf; m++) s_slot[off + m] = (unsigned short)((pos << 3) | m);
                 }
                 if (tid == 0) {
                     s_nfar = __popcll(f0) + 3 * __popcll(f1) + 5 * __popcll(f2) + 7 * __popcll(f3);  // far components of the chunk
                     if (f0 | f1 | f2 | f3) s_anyfar = 1;
                 }
             }
-            if (tid == 0) s_n = __popcll(mask);
+            if (tid == 0) s_n = n_near;
         }
         __syncthreads();
         KSTAMP(2);
         const int n = PROBE_SKIP(1) ? 0 : s_n;
         for (int q = 0; q < n; q++) {
-            const LdsMult &M = s_m[q];
-            if (FARFIELD && (M.flags & F_FAR)) continue;  // wave-uniform
+            const LdsMult &M = s_m[q];  // (near multiplets only: the staging pass put them first)
             switch (M.l) {  // wave-uniform
             case 0: mult_dispatch<FAST, 1, K>(M, xv, bin, acc, xc); break;
             case 1: mult_dispatch<FAST, 3, K>(M, xv, bin, acc, xc); break;
