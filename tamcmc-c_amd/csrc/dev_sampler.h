@@ -16,6 +16,9 @@ namespace tamcmc {
 struct DevSamplerArgs {
     ModelDesc desc;       // model_id, prior_class, Np, per, stride, Nx, grid, plength/priors/extra/poly pointers
     int C, Nv, ntiles, chol_in_lds;
+#ifdef TAMCMC_PROBE       // probe build only (tools/learn_probe.py): leave adapt_chain after phase N -- the chains are then WRONG, only times are read
+    int probe = 0;
+#endif
     int swap_rule;        // 1: chain B's stored logPosterior after a swap as MALA.cpp:433,444 execute it
     long pl;              // likelihood_params truncated to long (likelihoods.h:14)
     long dN_mixing;

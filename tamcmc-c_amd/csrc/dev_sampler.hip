@@ -31,6 +31,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "ctx.h"
@@ -46,6 +48,25 @@
 namespace tamcmc {
 
 namespace {
+
+// value of x in lane LANE (a compile-time constant) for every lane: v_readlane, no LDS round trip like __shfl
+template <int LANE>
+__device__ __forceinline__ double lane_value(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), LANE), hi = __builtin_amdgcn_readlane((int)(b >> 32), LANE);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a compile-time constant in every copy of its body,
+// so that small register arrays indexed by it stay in registers (`#pragma unroll` is a request the optimiser may turn down)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 __global__ void k_fill_poly(mt::PolyTab *t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) mt::fill_poly(*t);
@@ -170,8 +191,10 @@ __device__ __forceinline__ double wave_partial_sum(const double *base, int ntile
 
 // Robbins-Monro adaptation of chain m's proposal law (MALA.cpp:296-319) and Cholesky of (Sigma+eps2 I) sigma
 // (MALA.cpp:348-350); `vars` = the chain's position after the MH test, `Pm` = its move probability.
-__device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const double *vars, double Pm, double *A, double *d,
-                            double *s_red, double *s_scal) {
+// WP: pointer type of the work matrix A and the vector d in their address space (LDS when the matrix fits there: ds_read/ds_write
+// instead of flat accesses, whose latency is several times higher; device memory otherwise); PANELS: the blocked factorisation.
+template <class WP, bool PANELS>
+__device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const double *vars, double Pm, WP A, WP d, double *s_red, double *s_scal) {
     const int tid = threadIdx.x, Nv = a.Nv;
     const double g = a.c0 / (1. + (double)itp);
     double *mu = a.mu + (size_t)m * Nv;
@@ -193,13 +216,27 @@ __device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const doub
         }
     }
     __syncthreads();
+#ifdef TAMCMC_PROBE
+    if (a.probe == 1) return;
+#endif
+    // covariance update (MALA.cpp:313-316) and the matrix to factor, A = (Sigma + eps2 I) sigma, in one sweep over Sigma (device memory,
+    // read and written once); lanes as a 16 x 16 grid over (row, column): no index arithmetic per element, 128-byte runs per row
+    const int gi = tid >> 4, gk = tid & 15;
     n2 = 0;
-    for (int e = tid; e < Nv * Nv; e += TB) {
-        const int i = e / Nv, j = e - i * Nv;
-        const double v = cov[e] + g * (d[i] * d[j] - cov[e]);
-        cov[e] = v;
-        n2 += v * v;
+    for (int i = gi; i < Nv; i += 16) {
+        const double di = d[i];
+        for (int j = gk; j < Nv; j += 16) {
+            const size_t e = (size_t)i * Nv + j;
+            const double c = cov[e];
+            const double v = c + g * (di * d[j] - c);
+            cov[e] = v;
+            A[e] = v;
+            n2 += v * v;
+        }
     }
+#ifdef TAMCMC_PROBE
+    if (a.probe == 2) return;
+#endif
     n2 = wg_sum(n2, s_red);
     if (tid == 0) {
         const double nrm = sqrt(n2);
@@ -212,37 +249,184 @@ __device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const doub
     }
     __syncthreads();
     const double sc = s_scal[0], sig = s_scal[1];
-    for (int e = tid; e < Nv * Nv; e += TB) {
-        const int i = e / Nv, j = e - i * Nv;
-        double v = cov[e];
-        if (sc != 1.0) { v = v * sc; cov[e] = v; }
-        A[e] = (v + (i == j ? a.epsi2 : 0.0)) * sig;
-    }
+    for (int i = gi; i < Nv; i += 16)
+        for (int j = gk; j < Nv; j += 16) {
+            const size_t e = (size_t)i * Nv + j;
+            double v = A[e];
+            if (sc != 1.0) { v = v * sc; cov[e] = v; }  // (a covariance of norm > A1 = 1e14: never with sane inputs)
+            A[e] = (v + (i == j ? a.epsi2 : 0.0)) * sig;
+        }
     __syncthreads();
-    // right-looking Cholesky in place (lower triangle of A): column scale + trailing update per step.  A matrix that is not
-    // positive definite (possible only while gamma = c0/(1+i) > 1, i.e. adaptation before iteration c0) keeps the PREVIOUS
-    // factor -- the host engine does the same (host_mala.cpp::factor); the reference hands Eigen's partial result on.
-    for (int j = 0; j < Nv; j++) {
-        const double ajj = A[(size_t)j * Nv + j];  // workgroup-uniform
-        if (!(ajj > 0.0)) return;                  // every lane leaves together, L is not touched
-        const double djj = sqrt(ajj);
+#ifdef TAMCMC_PROBE
+    if (a.probe == 3) return;
+#endif
+    // Cholesky in place (lower triangle of A).  A matrix that is not positive definite (possible only while gamma = c0/(1+i) > 1,
+    // i.e. adaptation before iteration c0) keeps the PREVIOUS factor -- the host engine does the same (host_mala.cpp::factor); the
+    // reference hands Eigen's partial result on.  Every element sees the operations of the right-looking algorithm in its order
+    // (A_ik -= L_ij L_kj for j ascending, then / d_kk), so the factor is the host engine's bit for bit -- only the schedule differs:
+    //   * panels of NB columns: the NB x NB diagonal block is factored by NB lanes of one wave (rows in registers, pivots by
+    //     shuffles, no workgroup barrier inside); the panel's columns below it are one forward substitution per row, a row per lane;
+    //     then all lanes apply the NB columns to the trailing block in one sweep (a 16 x 16 grid over rows x columns, L_i,panel in
+    //     registers along a row).  3 barriers per panel instead of 3 per column; the serial chain is sqrt -> divide per column.
+    constexpr int NB = 8;
+    bool pd = true;  // positive definite so far
+    int j0 = 0;      // columns done by panels
+    const int ti = tid >> 4, tk = tid & 15;
+    if constexpr (PANELS) {
+        if (tid == 0) s_scal[0] = 0.0;  // "not positive definite" flag
         __syncthreads();
-        if (tid == 0) A[(size_t)j * Nv + j] = djj;
+        // one full panel of NB columns (no per-column guards: the LDS reads of a step are requested together)
+        auto panel = [&](const int p0) -> bool {
+            const int c0 = p0 + NB;
+#ifdef TAMCMC_PROBE
+            long pt0 = (long)wall_clock64();
+#endif
+            // (1) the panel's NB x NB diagonal block, by the first NB lanes of wave 0 (lane r = row p0+r in registers; pivots by readlane)
+            if (tid < 64) {
+                double r[NB];
+                const int row = p0 + tid;
+                static_for<NB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    r[c] = (tid < NB) ? A[(size_t)row * Nv + p0 + c] : 0.0;
+                });
+                bool bad = false;
+                static_for<NB>([&](auto jc) {
+                    constexpr int jj = decltype(jc)::value;
+                    if (!bad) {  // wave-uniform
+                        const double ajj = lane_value<jj>(r[jj]);
+                        if (!(ajj > 0.0)) bad = true;
+                        else {
+                            const double djj = sqrt(ajj);
+                            if (tid > jj) r[jj] = r[jj] / djj;
+                            else if (tid == jj) r[jj] = djj;
+                            static_for<NB - 1 - jj>([&](auto kc) {
+                                constexpr int kk = jj + 1 + decltype(kc)::value;
+                                const double lk = lane_value<kk>(r[jj]);  // L_(p0+kk),jj
+                                if (tid >= kk) r[kk] = r[kk] - r[jj] * lk;
+                            });
+                        }
+                    }
+                });
+                if (bad) { if (tid == 0) s_scal[0] = 1.0; }
+                else if (tid < NB)
+                    static_for<NB>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if (c <= tid) A[(size_t)row * Nv + p0 + c] = r[c];
+                    });
+            }
+            __syncthreads();
+            if (s_scal[0] != 0.0) return false;  // every lane leaves together, L is not touched
+#ifdef TAMCMC_PROBE
+            long pt1 = (long)wall_clock64();
+#endif
+            // (2) the panel's columns below the block, one row per lane: L_i,jj = (A_i,jj - sum_{j' < jj} L_i,j' L_jj,j') / d_jj
+#pragma clang loop unroll(disable)
+            for (int i = c0 + tid; i < Nv; i += TB) {
+                double li[NB], Ld[NB][NB];  // the row's panel entries and the diagonal block: every LDS read is requested before the first use
+                static_for<NB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    li[c] = A[(size_t)i * Nv + p0 + c];
+                    static_for<c + 1>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        Ld[c][q] = A[(size_t)(p0 + c) * Nv + p0 + q];
+                    });
+                });
+                static_for<NB>([&](auto jc) {
+                    constexpr int jj = decltype(jc)::value;
+                    static_for<jj>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        li[jj] = li[jj] - li[q] * Ld[jj][q];
+                    });
+                    li[jj] = li[jj] / Ld[jj][jj];
+                });
+                static_for<NB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    A[(size_t)i * Nv + p0 + c] = li[c];
+                });
+            }
+            __syncthreads();
+#ifdef TAMCMC_PROBE
+            long pt2 = (long)wall_clock64();
+#endif
+            // (3) the panel's NB columns applied to the trailing block (rows i >= c0, columns c0..i), lanes as a 16 x 16 grid
+#pragma clang loop unroll(disable)
+            for (int i = c0 + ti; i < Nv; i += 16) {
+                double li[NB];
+                static_for<NB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    li[c] = A[(size_t)i * Nv + p0 + c];
+                });
+                int k = c0 + tk;
+#pragma clang loop unroll(disable)
+                for (; k + 16 <= i; k += 32) {  // two columns per trip: their LDS reads are in flight together (one wave per SIMD here)
+                    double v0 = A[(size_t)i * Nv + k], v1 = A[(size_t)i * Nv + k + 16], l0[NB], l1[NB];
+                    static_for<NB>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        l0[c] = A[(size_t)k * Nv + p0 + c];
+                        l1[c] = A[(size_t)(k + 16) * Nv + p0 + c];
+                    });
+                    static_for<NB>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        v0 = v0 - li[c] * l0[c];
+                        v1 = v1 - li[c] * l1[c];
+                    });
+                    A[(size_t)i * Nv + k] = v0;
+                    A[(size_t)i * Nv + k + 16] = v1;
+                }
+                if (k <= i) {
+                    double v = A[(size_t)i * Nv + k];
+                    static_for<NB>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        v = v - li[c] * A[(size_t)k * Nv + p0 + c];
+                    });
+                    A[(size_t)i * Nv + k] = v;
+                }
+            }
+            __syncthreads();
+#ifdef TAMCMC_PROBE
+            if (m == 0 && tid == 0) {
+                const long pt3 = (long)wall_clock64();
+                a.counters[4] += pt1 - pt0; a.counters[5] += pt2 - pt1; a.counters[6] += pt3 - pt2; a.counters[7] += 1;
+            }
+#endif
+            return true;
+        };
+#pragma clang loop unroll(disable)
+        for (; j0 + NB <= Nv && pd; j0 += NB) pd = panel(j0);
+    }
+    // the columns the panels leave (fewer than NB; all of them for wide proposals, whose work matrix is in device memory): one per step
+#pragma clang loop unroll(disable)
+    for (int j = j0; j < Nv && pd; j++) {
+        const double ajj = A[(size_t)j * Nv + j];  // workgroup-uniform (its last update was before the previous step's closing barrier)
+        if (!(ajj > 0.0)) { pd = false; break; }   // every lane leaves together, L is not touched
+        const double djj = sqrt(ajj);
+        if (tid == 0) d[j] = djj;                  // the new diagonal is parked in d[] (free since the covariance update)
         for (int i = j + 1 + tid; i < Nv; i += TB) A[(size_t)i * Nv + j] = A[(size_t)i * Nv + j] / djj;
         __syncthreads();
-        const int rem = Nv - j - 1;
-        for (int e = tid; e < rem * rem; e += TB) {
-            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-            if (k <= i) A[(size_t)i * Nv + k] = A[(size_t)i * Nv + k] - A[(size_t)i * Nv + j] * A[(size_t)k * Nv + j];
+        for (int i = j + 1 + ti; i < Nv; i += 16) {
+            const double lij = A[(size_t)i * Nv + j];
+            for (int k = j + 1 + tk; k <= i; k += 16) A[(size_t)i * Nv + k] = A[(size_t)i * Nv + k] - lij * A[(size_t)k * Nv + j];
         }
         __syncthreads();
     }
-    double *LT = a.LT + (size_t)m * Nv * Nv;
-    for (int e = tid; e < Nv * Nv; e += TB) {
-        const int i = e / Nv, k = e - i * Nv;
-        LT[(size_t)k * Nv + i] = (k <= i) ? A[e] : 0.0;
-    }
+    if (pd)
+        for (int j = j0 + tid; j < Nv; j += TB) A[(size_t)j * Nv + j] = d[j];
     __syncthreads();
+#ifdef TAMCMC_PROBE
+    if (a.probe == 4) return;
+#endif
+    double *LT = a.LT + (size_t)m * Nv * Nv;  // the factor transposed (row k of LT = column k of L), written in 128-byte runs
+    if (pd)
+        for (int k = gi; k < Nv; k += 16)
+            for (int i = gk; i < Nv; i += 16) LT[(size_t)k * Nv + i] = (k <= i) ? A[(size_t)i * Nv + k] : 0.0;
+    __syncthreads();
+}
+__device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const double *vars, double Pm, double *A, double *d, double *s_red,
+                            double *s_scal) {
+    typedef double __attribute__((address_space(3))) *lds_dp_t;
+    typedef double __attribute__((address_space(1))) *dev_dp_t;
+    if (a.chol_in_lds) adapt_chain_as<lds_dp_t, true>(a, m, itp, vars, Pm, (lds_dp_t)A, (lds_dp_t)d, s_red, s_scal);
+    else adapt_chain_as<dev_dp_t, false>(a, m, itp, vars, Pm, (dev_dp_t)A, (dev_dp_t)d, s_red, s_scal);
 }
 
 // z ~ N(0, I) of (chain, iteration) into LDS (ends without a barrier) and row i of L z (MALA.cpp:348-355)
@@ -955,6 +1139,15 @@ DevSampler::~DevSampler() {
         (void)hipSetDevice(impl->ctx->device);
         (void)hipStreamSynchronize(impl->ctx->stream);
     }
+#ifdef TAMCMC_PROBE
+    if (impl->a.counters && getenv("TAMCMC_PROBE_ADAPT")) {
+        long h[8];
+        (void)hipMemcpy(h, impl->a.counters, sizeof h, hipMemcpyDeviceToHost);
+        if (h[7] > 0)
+            fprintf(stderr, "Cholesky panels of chain 0 (us per panel): diagonal block %.2f | columns below %.2f | trailing update %.2f  (%ld panels)\n",
+                    0.01 * h[4] / h[7], 0.01 * h[5] / h[7], 0.01 * h[6] / h[7], h[7]);
+    }
+#endif
     for (void *p : impl->allocs) (void)hipFree(p);
     impl->fd_block.release(); impl->fd_part.release(); impl->fd_S.release(); impl->fd_model.release(); impl->fd_bg.release();
     if (impl->h_pack) (void)hipHostFree(impl->h_pack);
@@ -990,6 +1183,9 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DevSamplerArgs &a = I.a;
     a.desc.model_id = in.model_id; a.desc.prior_class = in.prior_class; a.C = in.C; a.desc.Np = in.Np; a.Nv = in.Nv;
     I.rgb = is_rgb_model(in.model_id);
+#ifdef TAMCMC_PROBE
+    if (const char *ep = getenv("TAMCMC_PROBE_ADAPT")) a.probe = atoi(ep);
+#endif
     a.desc.per = I.rgb ? 0 : mt::count_multiplets(in.model_id, in.plength);
     I.h_plength.assign(in.plength, in.plength + 11);
     I.use_drift = in.use_drift != 0; I.delta = in.delta; I.fd_step_rel = in.fd_step_rel > 0 ? in.fd_step_rel : 1e-7;
