@@ -83,7 +83,8 @@ struct AcceptOut {
 
 // MALA.cpp:490-551 for one chain, by ONE lane: S = sum of the chain's per-tile partials, (logPr, status) = the proposal's prior and
 // table status, logPost_cur / logL_cur / logPr_cur = what the chain holds.  The same statement sequence serves both launch schemes.
-__device__ __forceinline__ AcceptOut mh_outcome(const DevSamplerArgs &a, int j, long itp, double S, double logPr, int status, double logL_cur,
+template <class AT>  // AT: DevSamplerArgs, or the same block read through a constant-memory reference (fused settle)
+__device__ __forceinline__ AcceptOut mh_outcome(const AT &a, int j, long itp, double S, double logPr, int status, double logL_cur,
                                                 double logPr_cur, double logPost_cur, double Tcoef, double init_logL) {
     double logL = (-(double)a.pl * S) / Tcoef;  // call_likelihood, model_def.cpp:399-401
     double logPost;
@@ -567,10 +568,12 @@ __device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int 
     }
 }
 
-__device__ __forceinline__ bool is_swap_iter(const DevSamplerArgs &a, long i) {
+template <class AT>
+__device__ __forceinline__ bool is_swap_iter(const AT &a, long i) {
     return a.dN_mixing > 0 && (i % a.dN_mixing == 0) && i != 0 && a.C > 1;
 }
-__device__ __forceinline__ int swap_first(const DevSamplerArgs &a, long i, double *u_out) {  // MALA.cpp:397-405
+template <class AT>
+__device__ __forceinline__ int swap_first(const AT &a, long i, double *u_out) {  // MALA.cpp:397-405
     double u, u2;
     rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)i, 0, u, u2);
     int A = (int)(u2 * (double)(a.C - 1));
@@ -581,7 +584,8 @@ __device__ __forceinline__ int swap_first(const DevSamplerArgs &a, long i, doubl
 
 // Parallel tempering (MALA.cpp:397-461) on the pair's outcomes AFTER their MH tests: does the pair swap, and what does each side
 // then hold as tempered logL / prior / posterior.  oA, oB are updated in place; returns 1 when swapped.
-__device__ __forceinline__ int resolve_swap(const DevSamplerArgs &a, int A, double u, AcceptOut &oA, AcceptOut &oB) {
+template <class AT>
+__device__ __forceinline__ int resolve_swap(const AT &a, int A, double u, AcceptOut &oA, AcceptOut &oB) {
     const int B = A + 1;
     const double LA = oA.logL, LB = oB.logL;
     const double LA_TB = LA * a.Tcoefs[A] / a.Tcoefs[B];
@@ -729,8 +733,21 @@ constexpr int NG = 8;                  // tile groups per chain (ticket level 1)
 constexpr int TKS = 32;                // unsigned per ticket line
 constexpr int TK = (1 + NG) * TKS;     // unsigned per chain
 
+// The settle functions are real calls (register budget) and get the argument blocks as pointers to their device-memory image.  That image
+// is written by the host only, and the pointer is the same in every lane: read through a wave-uniform pointer into constant memory, a
+// field costs a scalar load (SGPR, scalar cache) instead of a flat vector load per lane, and the pointers found there are known to be
+// global (global_load / global_store instead of flat_).
+typedef DevSamplerArgs __attribute__((address_space(4))) ConstArgs;
+typedef FusedArgs __attribute__((address_space(4))) ConstFused;
+__device__ __forceinline__ const void __attribute__((address_space(4))) *uniform_ptr(const void *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (const void __attribute__((address_space(4))) *)(((unsigned long long)hi << 32) | lo);
+}
+
 // The scalar part of a chain's settled state (ONE lane): what it holds, the slot of its next proposal, the record of its statistics.
-__device__ __forceinline__ void fused_scalars(const DevSamplerArgs &a, const FusedArgs &f, int m, int src_acc, double src_r, const AcceptOut &o,
+template <class AT, class FT>
+__device__ __forceinline__ void fused_scalars(const AT &a, const FT &f, int m, int src_acc, double src_r, const AcceptOut &o,
                                               int next_slot, long it, int q, long rec) {
     const int C = a.C, q1 = q ^ 1;
     a.logL_cur[q1 * C + m] = o.logL;
@@ -749,7 +766,8 @@ __device__ __forceinline__ void fused_scalars(const DevSamplerArgs &a, const Fus
 
 // Writes chain m's settled state for the next iteration: position = chain `src`'s post-test position (its own, or the swap partner's),
 // scalars from `o` (already re-tempered after a swap); records the sample; names the slot of chain m's next proposal.
-__device__ __forceinline__ void fused_finalize(const DevSamplerArgs &a, const FusedArgs &f, int m, int src, int src_acc, double src_r,
+template <class AT, class FT>
+__device__ __forceinline__ void fused_finalize(const AT &a, const FT &f, int m, int src, int src_acc, double src_r,
                                                const AcceptOut &o, int next_slot, long it, int q, long rec) {
     const int lane = threadIdx.x, C = a.C, Nv = a.Nv, Np = a.desc.Np, q1 = q ^ 1;
     const double *sv, *sp;
@@ -772,8 +790,8 @@ __device__ __forceinline__ void fused_finalize(const DevSamplerArgs &a, const Fu
 // resolves the swap (MALA.cpp:397-461) and writes both chains' settled states.
 __device__ __attribute__((noinline)) void fused_settle_pair(const DevSamplerArgs *ga, const FusedArgs *gf, int m, int A, double u, int o_acc, double o_r,
                                                             double o_logL, double o_logPr, double o_logPost, long it, int q, long rec) {
-    const DevSamplerArgs &a = *ga;
-    const FusedArgs &f = *gf;
+    const ConstArgs &a = *(const ConstArgs *)uniform_ptr(ga);
+    const ConstFused &f = *(const ConstFused *)uniform_ptr(gf);
     const int lane = threadIdx.x, C = a.C;
     AcceptOut o;
     o.acc = o_acc; o.r = o_r; o.logL = o_logL; o.logPr = o_logPr; o.logPost = o_logPost;
@@ -817,8 +835,8 @@ __device__ __attribute__((noinline)) void fused_settle_pair(const DevSamplerArgs
 // The chain's settle step, run by the wave of the chain's LAST tile (a real function call with pointer arguments, like the candidate
 // roles: inlined into the tile body it would raise the kernel's register allocation above three waves per SIMD).
 __device__ __attribute__((noinline)) void fused_settle(const DevSamplerArgs *ga, const FusedArgs *gf, int m, int ps, long it, int q, long rec) {
-    const DevSamplerArgs &a = *ga;
-    const FusedArgs &f = *gf;
+    const ConstArgs &a = *(const ConstArgs *)uniform_ptr(ga);
+    const ConstFused &f = *(const ConstFused *)uniform_ptr(gf);
     const int lane = threadIdx.x, C = a.C, Nv = a.Nv, Np = a.desc.Np;
     // Everything that does not depend on the sums is requested first (this wave is the launch's critical tail): the proposal's prior and
     // status, what the chain holds, and BOTH vectors the chain may continue from (its position and its proposal).
