@@ -1486,6 +1486,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         const int first = goff[g];
         fill_common(l, goff[g + 1] - goff[g]);
         l.mults = a.mults; l.offsets = a.pairs + 2 * first; l.noise = a.noise + (size_t)first * a.desc.stride;
+        l.per = a.desc.per; l.slot0 = first;  // (chain m's table is rows [m per, (m+1) per) of a.mults: dev_unpack.h, rgb_prestep.hip)
         l.nharvey = a.nh + first; l.nnoise = a.nn + first; l.partials = a.partials + (size_t)first * a.ntiles * 2;
         l.bg_poly = a.bg ? a.bg + (size_t)first * a.ntiles * 8 : nullptr;
     }
@@ -1497,6 +1498,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         l.nharvey = f.nh + (size_t)q * NS; l.nnoise = f.nn + (size_t)q * NS; l.partials = a.partials;
         l.bg_poly = f.bg ? f.bg + (size_t)q * NS * a.ntiles * 8 : nullptr;
         l.slot_map = f.slot + (size_t)q * C;
+        l.per = a.desc.per; l.slot0 = 0;
     }
 
     int used_ev = 0;

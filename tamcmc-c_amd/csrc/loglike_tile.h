@@ -226,7 +226,8 @@ struct __attribute__((aligned(16))) TileLds {
 // COH: the two partial sums are written through to memory (device-scope stores) because another workgroup of the SAME launch reads
 // them (the fused sampler step's settle tail); MI355X has one L2 per XCD and plain stores stay in the writer's.
 template <int MODE, int WGS, int K, bool WRITE_MODEL, bool DELTA, bool COH = false>
-__device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int tile, const int b, const int sb, TileLds<MODE, WGS> &S) {
+__device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int tile, const int b, const int sb, TileLds<MODE, WGS> &S, const int mbeg,
+                                             const int mend, const int nh, const int nn) {
     constexpr bool FAST = (MODE != M_STRICT);
     static_assert(!DELTA || (FAST && !WRITE_MODEL), "DELTA launches are FAST-mode, logL-only");
     constexpr bool FARFIELD = (MODE == M_FAST);
@@ -266,13 +267,11 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     }
 
     tamcmc_multiplet g;
-    const int mbeg = a.offsets[2 * sb], mend = a.offsets[2 * sb + 1];
-    // prebuilt background series of this (evaluation, tile): issued now, stored to LDS when the tile polynomial is set up
+    // prebuilt background series of this (evaluation, tile), one coefficient per lane: it stays in those lanes' registers and enters the
+    // tile polynomial where the far-field sums are closed (no wait for it here, no trip through LDS)
+    const bool bg_prebuilt = FARFIELD && !DELTA && a.bg_poly;
     double bg_pre = 0.0;
-    {
-        const int hl0 = (WGS > 64) ? tid - 64 : tid;
-        if (FARFIELD && !DELTA && a.bg_poly && hl0 >= 0 && hl0 < NH) bg_pre = a.bg_poly[((size_t)sb * a.ntiles + tile) * NH + hl0];
-    }
+    if (bg_prebuilt && tid < NH) bg_pre = a.bg_poly[((size_t)sb * a.ntiles + tile) * NH + tid];
     double xv[K], yv[K], acc[K];
     int bin[K];
 #pragma unroll
@@ -284,8 +283,6 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     }
 
     const double *nz = a.noise + (size_t)sb * a.noise_stride;
-    const int nh = a.nharvey[sb];
-    const int nn = a.nnoise[sb];
     // DELTA: background difference only when the noise parameters changed (same Harvey count on both sides)
     const bool bg = !DELTA || (a.d_flags[b] & 1);
     const double *nzo = DELTA ? a.d_noise_old + (size_t)b * a.noise_stride : nz;
@@ -305,7 +302,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
         if (tid < NC) s_coef[tid] = 0.0;
         if (tid == 0) s_anyfar = harvey_poly ? 1 : 0;
         __syncthreads();
-        if (harvey_poly) {
+        if (harvey_poly && !bg_prebuilt) {
             // lane = Harvey term (wave 1 when there are four waves: wave 0 is about to compact the first chunk); the NH
             // series coefficients of the terms are added to the tile polynomial in term order by the last of these lanes
             const int hl = (WGS > 64) ? tid - 64 : tid;
@@ -313,16 +310,13 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
 #pragma unroll
             for (int k = 0; k < NH; k++) f[k] = 0.0;
             const bool lane_new = (hl >= 0 && hl < nh), lane_old = DELTA && (hl >= 32 && hl < 32 + nh);
-            if (!DELTA && a.bg_poly) {
-                // the table builder already summed the series of this (evaluation, tile): bg_series.h, same arithmetic
-                if (hl >= 0 && hl < NH) s_coef[hl] = bg_pre;
-            } else if (lane_new || lane_old) {
+            if (lane_new || lane_old) {
                 const double *nq = lane_new ? nz : nzo;
                 const int ht = lane_new ? hl : hl - 32;
                 bg::harvey_term_series(lane_new ? nq[3 * ht] : -nq[3 * ht], nq[3 * ht + 1], nq[3 * ht + 2], xc, h, f);
             }
             // lanes hl = 0..nh-1 live in ONE wave: sum their series in lane order with shuffles, lane 0 adds the white noise
-            if ((DELTA || !a.bg_poly) && hl >= 0 && hl < 64) {
+            if (hl >= 0 && hl < 64) {
 #pragma unroll
                 for (int k = 0; k < NH; k++) {
                     double v = f[k];
@@ -337,13 +331,15 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
         }
     }
 
-    // the power values are only needed in the epilogue: issued here, their latency hides behind the multiplet loop
+    // the table builder already summed the series of this (evaluation, tile) (bg_series.h, same arithmetic): still in registers
+    bool bg_in_regs = harvey_poly && bg_prebuilt;
     KSTAMP(1);
     for (int c0 = mbeg; c0 < mend; c0 += CHUNK) {
         __syncthreads();  // previous chunk fully consumed
         if (tid < 64) {
             const int idx = c0 + tid;
-            g = a.mults[min(idx, mend - 1)];  // the whole row in ONE round trip (clamped index: lanes past the end stage nothing)
+            // the whole row in ONE round trip (clamped index: lanes past the end stage nothing); with a.per its address does not wait for the range
+            g = a.mults[a.per > 0 ? min(idx, mbeg + a.per - 1) : min(idx, mend - 1)];
             const int i0 = g.i0, i1 = g.i1;
             const bool ov = (idx < mend) && (i0 < t1) && (i1 > t0) && !PROBE_SKIP(16);
             // every overlapping multiplet is staged with its per-multiplet scalars hoisted: the NEAR ones first (in table order: the
@@ -497,13 +493,15 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
             }
             __syncthreads();
             if (tid < NC) {
-                double sum = s_coef[tid];
+                double sum = (bg_in_regs && tid < NH) ? bg_pre : s_coef[tid];  // background first, then the parts: the order of the sum
 #pragma unroll
                 for (int p = 0; p < WGS / 16; p++) sum = sum + s_part[p][tid];
                 s_coef[tid] = sum;
             }
+            bg_in_regs = false;
         }
     }
+    if (bg_in_regs && tid < NH) s_coef[tid] = bg_pre;  // (no far multiplet on this tile: the polynomial is the background alone)
     KSTAMP(4);
     // the power values: issued before the polynomial evaluation, consumed after it
 #pragma unroll
@@ -659,8 +657,13 @@ __device__ __forceinline__ void loglike_tile(const LoglikeArgs &a, const int id,
     tile += a.tile_rot;
     if (tile >= a.ntiles) tile -= a.ntiles;
     const int sb = a.slot_map ? (a.slot_map[b] & 0xffff) : b;
-    if (a.nnoise[sb] > 0)  // else: empty evaluation slot (a candidate that was not built, or whose table failed)
-        tile_compute<MODE, WGS, K, WRITE_MODEL, DELTA, Tail::coherent_partials>(a, tile, b, sb, S);
+    // everything the slot index leads to is requested at once (one memory round trip, not one per dependent step): the table's range,
+    // the noise row's lengths; a.per > 0 (device-built tables in fixed-size slots): the range begins at (slot0 + sb) * per
+    const int nn = a.nnoise[sb], nh = a.nharvey[sb];
+    const int mend = a.offsets[2 * sb + 1];
+    const int mbeg = a.per > 0 ? (a.slot0 + sb) * a.per : a.offsets[2 * sb];
+    if (nn > 0)  // else: empty evaluation slot (a candidate that was not built, or whose table failed)
+        tile_compute<MODE, WGS, K, WRITE_MODEL, DELTA, Tail::coherent_partials>(a, tile, b, sb, S, mbeg, mend, nh, nn);
     tail(b, tile, sb);
 }
 
