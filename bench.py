@@ -298,7 +298,7 @@ def main():
                                        "(proposal + prior, scalar unpack, solver, zeta, rows, likelihood, MH test: all enqueued, no host round trip)",
                            "host_driven_engine_samples_per_s": a.rgb_steps / e_host,
                            "accept_rate_chain0": float(racc[0]), "accept_rate_mean": float(racc.mean()),
-                           "roofline": {"bound": "hbm", "kernel": "k_loglike (40 evaluations x 2e5 bins per launch; the pre-step kernels are not in this time)",
+                           "roofline": {"bound": "hbm", "kernel": "k_loglike (one launch per chain group: 10 evaluations x 2e5 bins, the groups' launches overlap; the pre-step kernels are not in this time)",
                                         "kernel_us_per_launch": r_ms / max(r_l, 1) * 1e3, "evaluations_per_launch": r_e / max(r_l, 1),
                                         "algorithmic_bytes_per_launch": r_bytes / max(r_l, 1), "achieved": r_bytes / max(r_ms * 1e-3, 1e-12) / 1e9,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_bytes / max(r_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS}}
