@@ -711,7 +711,10 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
 // ===============================================================================================================
 // (A) FUSED STEP.
 struct FusedArgs {
-    int NS;                // candidate slots per iteration: 2C + 4
+    int NS;                // candidate slots per iteration: 2C + 8 (two blocks of four extra slots for a swap pair's cross candidates)
+    int xsplit;            // first chain of the second chain group (C: none).  A chain's cross candidates after a swap live in extra block
+                           // (chain >= xsplit), a pair (A, A+1) uses pair counter (A >= xsplit): the two groups' launches run on
+                           // different streams, possibly several iterations apart, and must never write what the other one still reads
     // candidates of the iteration with parity q: [2][NS]...
     double *cand_vars, *cand_params, *cand_logPr;
     int *cand_stP, *cand_stR;          // status of the prior role / the rows role
@@ -724,7 +727,7 @@ struct FusedArgs {
     unsigned *ticket;                  // [2][C][TK] two levels: [0] counts the chain's tile GROUPS that are complete, [1 + g] the tiles
                                        //          of group g = tile mod NG that have delivered their partial sums; one 128-byte line
                                        //          each (device-scope atomics on one line serialise in the memory-side atomic unit)
-    unsigned *pair_ticket;             // [2]      chains of the swap pair that have done their MH test
+    unsigned *pair_ticket;             // [2][2]   (parity, extra block) chains of the swap pair that have done their MH test
     double *acc;                       // [2][C][5] MH outcome of chain m (acc, r, logL, logPr, logPost), read by the partner that resolves the swap
 };
 
@@ -802,7 +805,8 @@ __device__ __attribute__((noinline)) void fused_settle_pair(const DevSamplerArgs
     }
     drain_memory_ops();
     unsigned first = 0;
-    if (lane == 0) first = atomicAdd(&f.pair_ticket[q], 1u);
+    const int xb = (A >= f.xsplit) ? 1 : 0;  // the pair's extra block
+    if (lane == 0) first = atomicAdd(&f.pair_ticket[2 * q + xb], 1u);
     first = __shfl(first, 0, 64);
     if (first == 0) return;  // the partner is still being evaluated: its last tile does the rest
     const int partner = (m == A) ? A + 1 : A;
@@ -824,8 +828,8 @@ __device__ __attribute__((noinline)) void fused_settle_pair(const DevSamplerArgs
     }
     const int B = A + 1;
     if (swapped) {  // each side continues from the other's post-test position: the extra candidate slots 2C .. 2C+3
-        fused_finalize(a, f, A, B, accB, rB, oA, 2 * C + accB, it, q, rec);
-        fused_finalize(a, f, B, A, accA, rA, oB, 2 * C + 2 + accA, it, q, rec);
+        fused_finalize(a, f, A, B, accB, rB, oA, 2 * C + (A >= f.xsplit ? 4 : 0) + accB, it, q, rec);
+        fused_finalize(a, f, B, A, accA, rA, oB, 2 * C + (B >= f.xsplit ? 4 : 0) + 2 + accA, it, q, rec);
     } else {
         fused_finalize(a, f, A, A, accA, rA, oA, 2 * A + accA, it, q, rec);
         fused_finalize(a, f, B, B, accB, rB, oB, 2 * B + accB, it, q, rec);
@@ -896,10 +900,10 @@ struct SettleTail {
     const DevSamplerArgs *ga;
     const FusedArgs *gf;
     long it, rec;
-    int q;
+    int q, first;  // first: chain of the launch's evaluation 0 (a launch covers the chains of one group, or all of them)
     static constexpr bool coherent_partials = true;
-    __device__ __forceinline__ void operator()(int m, int tile, int ps) const {
-        const int lane = threadIdx.x, C = a.C;
+    __device__ __forceinline__ void operator()(int b, int tile, int ps) const {
+        const int lane = threadIdx.x, C = a.C, m = first + b;
         drain_memory_ops();  // this tile's two partial sums (write-through stores) are in memory before the ticket counts the tile
         unsigned *tk = f.ticket + ((size_t)q * C + m) * TK;
         const int g = tile % NG, in_group = (a.ntiles - g + NG - 1) / NG;  // tiles g, g+NG, ... < ntiles
@@ -987,17 +991,20 @@ __device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, cons
     const int C = a.C, Nv = a.Nv, Np = a.desc.Np, tid = threadIdx.x;
     int m, src, on_prop;
     if (slot < 2 * C) { m = slot >> 1; src = m; on_prop = slot & 1; }
-    else {
+    else {  // slot = 2C + e, e = 0..3: the pair's cross candidates, stored in the pair's extra block
         if (entry || !is_swap_iter(a, itn - 1)) return;
         const int A = swap_first(a, itn - 1, nullptr), e = slot - 2 * C;
         m = (e < 2) ? A : A + 1;
         src = (e < 2) ? A + 1 : A;
         on_prop = e & 1;
+        slot += (m >= f.xsplit) ? 4 : 0;  // in the extra block of the chain that will use it (the group that owns that block never runs
+                                          // ahead of itself; the OTHER group's launches may be several iterations ahead)
     }
     if (entry && on_prop) return;  // a stretch starts from settled chains: there is no pending proposal to build on
     if (role == 0 && slot < 2 * C && !on_prop && tid == 0) {  // housekeeping for the launch that evaluates these candidates
         for (int g = 0; g <= NG; g++) f.ticket[((size_t)q_dst * C + m) * TK + g * TKS] = 0u;
-        if (m == 0) f.pair_ticket[q_dst] = 0u;
+        // (by the first chain of iteration itn's swap pair: with chain groups that chain's launches are the ones that use the counter)
+        if (is_swap_iter(a, itn) && m == swap_first(a, itn, nullptr)) f.pair_ticket[2 * q_dst + (m >= f.xsplit ? 1 : 0)] = 0u;
         if (entry) f.slot[q_dst * C + m] = 2 * m;
     }
     double *s_params = (double *)lds;
@@ -1036,7 +1043,9 @@ struct StepCtl {
     long it, rec, it_lz;   // iteration of the tiles / candidates; record index (-1: none); first iteration of the L z blocks
     int q, flags;          // parity of iteration `it`; ST_* bits
     int nbr, nlz;          // workgroups reserved for candidate roles / L z blocks (multiples of 8: keeps the tiles' XCD mapping)
-    int n_lz_live, q_lz;   // L z blocks that have work (chain e % C of iteration it_lz + e / C); parity of it_lz
+    int n_lz_live, q_lz;   // L z blocks that have work (chain first + e % cnt of iteration it_lz + e / cnt); parity of it_lz
+    int first, cnt;        // the chains of this launch: [first, first + cnt) -- all of them, or one chain group (see run(): fused)
+    int extra;             // 1: the launch also builds the four extra candidates of its iteration's swap pair (slots 2C..2C+3)
     const DevSamplerArgs *ga;  // device-memory copies of the first two kernel arguments (for the candidate roles' function calls)
     const struct FusedArgs *gf;
 };
@@ -1047,18 +1056,21 @@ struct StepCtl {
     __shared__ tile::TileLds<MODE, 64> lds;                                                                                  \
     const int id = (int)blockIdx.x;                                                                                          \
     if (id < c.nbr) {                                                                                                        \
-        if (c.flags & ST_ENTRY) candidate_role(a, f, c.ga, c.gf, c.it, c.q, c.q, id >> 2, id & 3, true, (unsigned char *)&lds); \
+        const int k = id >> 2, slot = k < 2 * c.cnt ? 2 * c.first + k : 2 * a.C + (k - 2 * c.cnt); /* the group's slots, then the pair's */ \
+        if (k >= 2 * c.cnt && !c.extra) return;                                                                              \
+        if (c.flags & ST_ENTRY) candidate_role(a, f, c.ga, c.gf, c.it, c.q, c.q, slot, id & 3, true, (unsigned char *)&lds);    \
         else if (c.flags & ST_BR)                                                                                            \
-            candidate_role(a, f, c.ga, c.gf, c.it + 1, c.q, c.q ^ 1, id >> 2, id & 3, false, (unsigned char *)&lds);           \
+            candidate_role(a, f, c.ga, c.gf, c.it + 1, c.q, c.q ^ 1, slot, id & 3, false, (unsigned char *)&lds);              \
         return;                                                                                                              \
     }                                                                                                                        \
     if (id < c.nbr + c.nlz) {                                                                                                \
         const int e = id - c.nbr;                                                                                            \
-        if (e < c.n_lz_live) lz_block(c.ga, c.gf, c.it_lz + e / a.C, (c.q_lz ^ (e / a.C)) & 1, e % a.C, (unsigned char *)&lds); \
+        if (e < c.n_lz_live)                                                                                                 \
+            lz_block(c.ga, c.gf, c.it_lz + e / c.cnt, (c.q_lz ^ (e / c.cnt)) & 1, c.first + e % c.cnt, (unsigned char *)&lds);  \
         return;                                                                                                              \
     }                                                                                                                        \
     if (c.flags & ST_L)                                                                                                      \
-        tile::loglike_tile<MODE, 64, K, false, false>(la, id - c.nbr - c.nlz, lds, SettleTail{a, f, c.ga, c.gf, c.it, c.rec, c.q});
+        tile::loglike_tile<MODE, 64, K, false, false>(la, id - c.nbr - c.nlz, lds, SettleTail{a, f, c.ga, c.gf, c.it, c.rec, c.q, c.first});
 // The tile path of K <= 8 bins per lane fits 168 VGPRs = three waves per SIMD; the candidate roles (log-prior, series) would raise the
 // kernel's allocation above that, so the occupancy is pinned here (those roles are separate functions, see candidate_role).
 template <int MODE, int K>
@@ -1129,6 +1141,8 @@ struct DevSampler::Impl {
     long armed_it = -1;
     int armed_q = 0;
 
+    hipEvent_t gev[8][2];  // fused step with two chain groups: event pairs around sampled launches of the second group (on its stream)
+    int n_gev = 0;
     bool rgb = false;  // ids 25 / 27: k_iterate leaves the table to the pre-step kernels (rgb_device_stage), lockstep scheme
     int rgb_bmax = 0;  // chains per workspace slice (one slice per chain group)
     bool fused_ok = false;
@@ -1170,6 +1184,7 @@ DevSampler::~DevSampler() {
     impl->fd_block.release(); impl->fd_part.release(); impl->fd_S.release(); impl->fd_model.release(); impl->fd_bg.release();
     if (impl->h_pack) (void)hipHostFree(impl->h_pack);
     for (int i = 0; i < impl->n_ev; i++) { (void)hipEventDestroy(impl->ev[i][0]); (void)hipEventDestroy(impl->ev[i][1]); }
+    for (int i = 0; i < impl->n_gev; i++) { (void)hipEventDestroy(impl->gev[i][0]); (void)hipEventDestroy(impl->gev[i][1]); }
     if (impl->ev_made) {
         (void)hipEventDestroy(impl->ev_fork);
         for (int g = 0; g < 4; g++) { (void)hipEventDestroy(impl->ev_kb[g]); (void)hipEventDestroy(impl->ev_ki[g]); (void)hipEventDestroy(impl->ev_join[g]); }
@@ -1279,6 +1294,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(hipGetLastError());
     a.desc.poly = d_tab;
     for (int i = 0; i < 64; i++) { DCHK(hipEventCreate(&I.ev[i][0])); DCHK(hipEventCreate(&I.ev[i][1])); I.n_ev = i + 1; }
+    for (int i = 0; i < 8; i++) { DCHK(hipEventCreate(&I.gev[i][0])); DCHK(hipEventCreate(&I.gev[i][1])); I.n_gev = i + 1; }
     {
         const int G = I.G;
         I.gst[0] = st;
@@ -1293,13 +1309,17 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     }
     {  // (A) fused step: 2C+4 candidate slots per iteration parity, tickets, outcomes (tables are sized at the first run())
         FusedArgs &f = I.f;
-        f.NS = 2 * in.C + 4;
+        f.NS = 2 * in.C + 8;
+        {   // two chain groups for the fused step (see run()): with the default groups, from 8 chains on
+            const int h = (int)(((long)in.C * 1) / 2);
+            f.xsplit = (I.G == 2 && h >= 3 && in.C - h >= 3) ? h : in.C;
+        }
         const size_t NS = (size_t)f.NS;
         DCHK(I.dalloc(&f.cand_vars, 2 * NS * Nv)); DCHK(I.dalloc(&f.cand_params, 2 * NS * Np)); DCHK(I.dalloc(&f.cand_logPr, 2 * NS));
         DCHK(I.dalloc(&f.cand_stP, 2 * NS)); DCHK(I.dalloc(&f.cand_stR, 2 * NS));
         DCHK(I.dalloc(&f.mults, 2 * NS * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&f.pairs, 4 * NS)); DCHK(I.dalloc(&f.nh, 2 * NS)); DCHK(I.dalloc(&f.nn, 2 * NS));
         DCHK(I.dalloc(&f.noise, 2 * NS * (size_t)a.desc.stride));
-        DCHK(I.dalloc(&f.slot, 2 * C)); DCHK(I.dalloc(&f.ticket, 2 * C * TK)); DCHK(I.dalloc(&f.lz, 2 * C * Nv)); DCHK(I.dalloc(&f.pair_ticket, 2)); DCHK(I.dalloc(&f.acc, 2 * C * 5));
+        DCHK(I.dalloc(&f.slot, 2 * C)); DCHK(I.dalloc(&f.ticket, 2 * C * TK)); DCHK(I.dalloc(&f.lz, 2 * C * Nv)); DCHK(I.dalloc(&f.pair_ticket, 4)); DCHK(I.dalloc(&f.acc, 2 * C * 5));
         DCHK(hipMemsetAsync(f.nn, 0, 2 * NS * sizeof(int), st));
         DCHK(hipMemsetAsync(f.cand_stP, 0, 2 * NS * sizeof(int), st));
         DCHK(hipMemsetAsync(f.cand_stR, 0, 2 * NS * sizeof(int), st));
@@ -1503,6 +1523,10 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
 
     int used_ev = 0;
     std::vector<std::pair<int, long>> fused_ev;  // (event pair, launches it brackets) of the fused stretches of this call
+    // fused step with two chain groups: the launches of an iteration overlap, so the stretch's elapsed time is not a launch duration;
+    // sampled launches of the second group are bracketed on their own stream instead
+    int g_used = 0;            // gev pairs used in this call
+    long g_launches = 0, g_iters = 0;  // launches / iterations of the split stretches of this call
     int P = I.parity;
     double kernel_ms = 0;
     long n_launch = 0, n_eval = 0;
@@ -1613,9 +1637,8 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     auto fused = [&](long ia, long ib) -> int {
         const FusedArgs &f = I.f;
         const int nbr = 4 * f.NS;                                     // candidate roles, a multiple of 8 (keeps the tiles' XCD mapping)
-        const int nlz1 = ((a.C + 7) / 8) * 8, nlz2 = ((2 * a.C + 7) / 8) * 8;
+        const int nlz2 = ((2 * a.C + 7) / 8) * 8;
         const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
-        const int grid_tiles = ntiles_pad * a.C;
         const long len = ib - ia;
         int q = P;
         StepCtl sc{};
@@ -1634,6 +1657,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             sc.ga = (const DevSamplerArgs *)I.d_argcopy;
             sc.gf = (const FusedArgs *)(I.d_argcopy + n1);
         }
+        sc.first = 0; sc.cnt = a.C; sc.extra = 1;
         if (!(I.armed_it == it0 + ia && I.armed_q == q)) {
             // entry: L z of the first two iterations, then the candidates of iteration ia built on the settled chains (state of parity q)
             sc.it = it0 + ia; sc.rec = -1; sc.q = q; sc.flags = ST_LZ; sc.nbr = 0; sc.nlz = nlz2; sc.n_lz_live = 2 * a.C; sc.it_lz = it0 + ia; sc.q_lz = q;
@@ -1641,30 +1665,81 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             sc.flags = ST_ENTRY; sc.nbr = nbr; sc.nlz = 0; sc.n_lz_live = 0;
             DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[q], sc));
         }
-        // the likelihood kernel's time for the roofline: two events around the whole stretch (launches back to back on one stream),
-        // i.e. the average includes the ~1.4 us between two launches
+        // the likelihood kernel's time for the roofline: two events around the whole stretch, i.e. the average includes the time between
+        // two launches
         const bool timed = c->timing && fused_ev.size() < 16;
         const int fe = I.n_ev - 1 - (int)fused_ev.size();
         if (timed) DCHK(hipEventRecord(I.ev[fe][0], st));
-        for (long i = ia; i < ib; i++) {
+        // Two chain groups, each with its own launch per iteration on its own stream: a launch is a chain of dependent steps (slot ->
+        // table rows -> tile -> ticket -> settle, ~20 us even for five chains) that leaves most of the GPU idle at its two ends; the two
+        // groups' launches fill each other's ends (two 10-chain stars side by side: 24.2 us per iteration each, one 20-chain launch: 27.8).
+        // Nothing is shared between the groups' launches except at a swap whose pair straddles the groups: that iteration is ONE launch
+        // over all chains on the context stream, with an event each way.  (Same chains bit for bit: the launches' contents are the same.)
+        const bool split = f.xsplit < a.C;
+        const int first1 = f.xsplit;
+        hipStream_t s1 = I.gst[1];
+        long n_split = 0;
+        bool s1_ahead = false, s1_must_wait = true;  // s1 holds launches st has not waited for / s1 has not seen st's latest launches
+        auto swap_pair_of = [&](long it) -> int {
+            if (!(a.C >= 2 && a.dN_mixing > 0 && (it % a.dN_mixing == 0) && it != 0)) return -1;
+            double u, u2;
+            rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)it, 0, u, u2);
+            int A = (int)(u2 * (double)(a.C - 1));
+            if (A > a.C - 2) A = a.C - 2;
+            return A;
+        };
+        auto launch_group = [&](int first, int cnt, int A, long i, hipStream_t stream) -> int {
             // every launch also prepares the next iteration's candidates and the L z after that -- the last one too (see armed_it)
+            const bool owns_pair = A >= first && A + 1 < first + cnt;
             sc.it = it0 + i; sc.rec = (samples || stats) ? i : (long)-1; sc.q = q;
             sc.flags = ST_L | ST_BR | ST_LZ;
-            sc.nbr = nbr; sc.nlz = nlz1; sc.n_lz_live = a.C; sc.it_lz = it0 + i + 2; sc.q_lz = q;
+            sc.first = first; sc.cnt = cnt; sc.extra = owns_pair ? 1 : 0;
+            sc.nbr = 4 * (2 * cnt + (owns_pair ? 4 : 0)); sc.nlz = ((cnt + 7) / 8) * 8; sc.n_lz_live = cnt; sc.it_lz = it0 + i + 2; sc.q_lz = q;
             LoglikeArgs lq = lf[q];
-            if (a.C >= 3 && a.dN_mixing > 0 && ((it0 + i) % a.dN_mixing == 0) && it0 + i != 0) {  // this iteration's swap pair leads the launch
-                double u, u2;
-                rng_uniform2(a.seed, RNG_SWAP, 0, (uint64_t)(it0 + i), 0, u, u2);
-                int A = (int)(u2 * (double)(a.C - 1));
-                if (A > a.C - 2) A = a.C - 2;
-                lq.prio_b = A;
+            lq.B = cnt;
+            lq.slot_map = lf[q].slot_map + first;
+            lq.partials = lf[q].partials + (size_t)first * a.ntiles * 2;
+            if (owns_pair && cnt >= 3) lq.prio_b = A - first;  // this iteration's swap pair leads the launch
+            DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + ntiles_pad * cnt, stream, args, f, lq, sc));
+            return TAMCMC_OK;
+        };
+        for (long i = ia; i < ib; i++) {
+            const int A = swap_pair_of(it0 + i);
+            if (split && A != first1 - 1) {
+                if (s1_must_wait) {
+                    DCHK(hipEventRecord(I.ev_fork, st));
+                    DCHK(hipStreamWaitEvent(s1, I.ev_fork, 0));
+                    s1_must_wait = false;
+                }
+                int rc = launch_group(0, first1, A, i, st);
+                if (rc) return rc;
+                const bool sample = timed && g_used < I.n_gev && (len >= 97 ? ((i - ia) % 97 == 48) : (i - ia == len / 2));
+                if (sample) DCHK(hipEventRecord(I.gev[g_used][0], s1));
+                rc = launch_group(first1, a.C - first1, A, i, s1);
+                if (rc) return rc;
+                if (sample) { DCHK(hipEventRecord(I.gev[g_used][1], s1)); g_used++; }
+                s1_ahead = true;
+                n_split++;
+            } else {
+                if (s1_ahead) {
+                    DCHK(hipEventRecord(I.ev_join[1], s1));
+                    DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
+                    s1_ahead = false;
+                }
+                int rc = launch_group(0, a.C, A, i, st);
+                if (rc) return rc;
+                s1_must_wait = true;
             }
-            DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + grid_tiles, st, args, f, lq, sc));
             q ^= 1;
+        }
+        if (s1_ahead) {
+            DCHK(hipEventRecord(I.ev_join[1], s1));
+            DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
         }
         if (timed) {  // (read after the call's final synchronisation)
             DCHK(hipEventRecord(I.ev[fe][1], st));
-            fused_ev.push_back({fe, len});
+            if (n_split == 0) fused_ev.push_back({fe, len});
+            else { g_launches += 2 * n_split + (len - n_split); g_iters += len; }
         }
         P = q;
         I.armed_it = it0 + ib;
@@ -1707,6 +1782,19 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         kernel_ms += ms;
         n_launch += e.second;
         n_eval += e.second * (long)a.C;
+    }
+    if (g_launches > 0) {  // split stretches: (average duration of the sampled launches) x (launches); one launch = one group's chains
+        double tot = 0;
+        for (int e = 0; e < g_used; e++) {
+            float ms = 0;
+            DCHK(hipEventElapsedTime(&ms, I.gev[e][0], I.gev[e][1]));
+            tot += ms;
+        }
+        if (g_used > 0) {
+            kernel_ms += tot / g_used * (double)g_launches;
+            n_launch += g_launches;
+            n_eval += g_iters * (long)a.C;
+        }
     }
     c->kernel_ms += kernel_ms;
     c->launches += n_launch;

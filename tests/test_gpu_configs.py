@@ -116,6 +116,29 @@ def test_c5_forty_chain_sampler_run(pkg, synth, engine):
     s.close(); ctx.close()
 
 
+def test_headline_shape_two_group_fused_steps_equal_the_lockstep_chain(pkg, synth):
+    """C3 (1e5 bins, 20 chains, swaps every iteration): 1500 acquire iterations as fused steps -- two launches per iteration, one per
+    chain group on its own stream, one joint launch whenever the swap pair straddles the groups -- against the lockstep kernels, and
+    against themselves a second time: identical samples and statistics (the groups' launches drift several iterations apart between
+    two joint iterations; nothing one group writes may be read by the other before they meet)."""
+    star, ctx = _c3_with_spectrum(pkg, synth, 0)
+    kw = dict(nchains=20, lambda_temp=1.3, seed=11, engine="device", Nt_learn=(10, 60), periods_learn=(1,), dN_mixing=1, c0=2.0)
+    runs = []
+    for scheme in (1, 0, 0):
+        ctx.set_option(pkg.OPT_STEP_SCHEME, scheme)
+        s = pkg.Sampler(ctx, star, **kw)
+        a1, b1 = s.run(100, stats=True)
+        a2, b2 = s.run(1500, stats=True)
+        runs.append((np.concatenate([a1, a2]), np.concatenate([b1, b2]), s.state()))
+        s.close()
+    ctx.set_option(pkg.OPT_STEP_SCHEME, 0)
+    for k in (1, 2):
+        assert np.array_equal(runs[k][0], runs[0][0]) and np.array_equal(runs[k][1], runs[0][1]), k
+        assert runs[k][2]["swaps"] == runs[0][2]["swaps"] and np.array_equal(runs[k][2]["vars"], runs[0][2]["vars"])
+    assert 100 < runs[0][2]["swaps"] < 1599
+    ctx.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -55,21 +55,24 @@ def test_device_engine_follows_host_engine(pkg, oracle, synth, ctx):
     h.close(); d.close()
 
 
-@pytest.mark.parametrize("dN_mixing,learn", [(1, None), (3, None), (7, (40, 90)), (0, None), (1, (5, 30))])
-def test_fused_steps_are_bitwise_the_lockstep_chain(pkg, oracle, synth, ctx, dN_mixing, learn):
+@pytest.mark.parametrize("nchains,dN_mixing,learn", [(7, 1, None), (7, 3, None), (7, 7, (40, 90)), (7, 0, None), (7, 1, (5, 30)),
+                                                     (12, 1, None), (20, 1, (40, 90)), (9, 2, None), (8, 1, None)])
+def test_fused_steps_are_bitwise_the_lockstep_chain(pkg, oracle, synth, ctx, nchains, dN_mixing, learn):
     """Stretches without adaptation run one fused launch per iteration (k_step: likelihood tiles with the settle step in their tail +
     the branch-ahead candidates of the next iteration); the lockstep kernels (k_iterate, k_loglike) do the same work in sequence.
     Same random numbers, same arithmetic, same summation orders: samples, statistics, swap counts and the final state must be
-    IDENTICAL, whatever the mixing period and wherever the adaptation window falls."""
+    IDENTICAL, whatever the mixing period and wherever the adaptation window falls.  From 8 chains on the fused iteration is TWO
+    launches, one per chain group on its own stream (the groups drift apart and meet again at every swap whose pair straddles them):
+    still the same chains."""
     star = _star_with_data(pkg, oracle, synth)
     ctx.set_spectrum(star.x, star.y)
     Nt = learn if learn else (10**9, 10**9 + 1)
-    kw = dict(nchains=7, lambda_temp=1.4, seed=23, Nt_learn=Nt, periods_learn=(2,), dN_mixing=dN_mixing)
+    kw = dict(nchains=nchains, lambda_temp=1.4 if nchains < 10 else 1.2, seed=23, Nt_learn=Nt, periods_learn=(2,), dN_mixing=dN_mixing)
     out = []
     for scheme in (1, 0):
         ctx.set_option(pkg.OPT_STEP_SCHEME, scheme)
         d = pkg.Sampler(ctx, star, engine="device", **kw)
-        s1, t1 = d.run(150, stats=True)
+        s1, t1 = d.run(150 if nchains < 8 else 700, stats=True)
         s2, t2 = d.run(61, stats=True)   # a second call continues the same chains
         s3, t3 = d.run(2, stats=True)    # shorter than a fused stretch: lockstep either way
         out.append((np.concatenate([s1, s2, s3]), np.concatenate([t1, t2, t3]), d.state()))
