@@ -7,6 +7,7 @@ src = f"gpurun_out/prof_{tag}"
 KERNEL = "k_step<1, 8>"          # the dominant kernel of the headline run: fused step, FAST arithmetic, 8 bins per lane
 os.makedirs("profiles", exist_ok=True)
 lines = [f"# rocprofv3 summary {tag} (MI355X, one GPU)", ""]
+kb = {}
 
 
 def newest(pattern):
@@ -23,7 +24,7 @@ ks = newest(f"{src}/trace/*/*kernel_stats.csv")
 if ks:
     lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --headline-only`", "",
               "(set-up phase = 1500 burn-in + learning iterations, 1000 of them with adaptation -> `k_iterate`/`k_loglike` lockstep launches; "
-              "warm-up 200 + timed 5000 acquire iterations -> one `k_step` launch each)", "",
+              "warm-up 200 + timed 5000 acquire iterations -> two `k_step` launches each, one per chain group on its own stream, or one joint launch when the swap pair straddles the groups)", "",
               "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks[0])):
         lines.append(f"| `{r['Name'][:110]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.2f} | "
@@ -32,6 +33,7 @@ if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
 try:
     b = json.loads(open(f"{src}/bench.json").read())
+    kb = b.get("roofline", {}).get("kernel", {})
     lines += ["## `python3 bench.py` line of the same build (un-profiled default run, all legs)", "", "```json", json.dumps(b, indent=1), "```", ""]
 except Exception as e:
     lines += [f"(no bench.json: {e})", ""]
@@ -60,12 +62,13 @@ if agg:
         lines.append(f"| {k} | {mean[k]:.4g} |")
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         hbm = (2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0
-        lines += ["", f"HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB = **{hbm/1e6:.2f} MB** against 32 MB algorithmic "
-                      "(16 B x 1e5 bins x 20 evaluations): the spectrum is served from the XCDs' L2s; what reaches the fabric is mostly the "
+        lines += ["", f"HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB = **{hbm/1e6:.2f} MB** against "
+                      f"{(kb.get('algorithmic_bytes_per_launch') or 0)/1e6:.1f} MB algorithmic (16 B x 1e5 bins x {kb.get('evaluations_per_launch') or 0:.2f} evaluations "
+                      "per launch on average; an iteration is two launches): the spectrum is served from the XCDs' L2s; what reaches the fabric is mostly the "
                       "candidates' tables and background series (written by the roles, read by the next launch's tiles) and the write-through partial sums."]
         json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": mean["FETCH_SIZE"], "write_size_kb": mean["WRITE_SIZE"],
                    "correction": "FETCH_SIZE x2 (gfx950; verified for 8-byte-per-lane loads with tools/pmc_calib.hip in the same session)",
-                   "kernel": KERNEL, "evaluations_per_launch": 20, "algorithmic_bytes_per_launch": 32.0e6,
+                   "kernel": KERNEL, "evaluations_per_launch": kb.get("evaluations_per_launch"), "algorithmic_bytes_per_launch": kb.get("algorithmic_bytes_per_launch"),
                    "source": f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --headline-only "
                              f"--steps 300, kernel {KERNEL}, FETCH_SIZE x2 (gfx950, calibrated on 8-byte-per-lane reads); not re-measured live"},
                   open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
