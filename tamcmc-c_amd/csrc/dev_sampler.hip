@@ -1155,6 +1155,22 @@ struct DevSampler::Impl {
     bool ev_made = false;
     double *d_pack = nullptr, *h_pack = nullptr;  // state download: device gather block and its pinned host image
 
+    // The caller's record buffer as the device sees it when it is pinned, mapped host memory (tamcmc_hip_host_alloc): the settle step then
+    // writes the records straight into it (15 KB per iteration over PCIe, posted) and a call ends without its two device-to-host copies.
+    const void *zc_host[2] = {nullptr, nullptr};
+    double *zc_dev[2] = {nullptr, nullptr};
+    double *device_view(int which, const double *host) {
+        if (!host) return nullptr;
+        if (zc_host[which] == host) return zc_dev[which];
+        hipPointerAttribute_t at;
+        double *d = nullptr;
+        if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) d = (double *)at.devicePointer;
+        else (void)hipGetLastError();  // (pageable memory: not an error for us)
+        zc_host[which] = host;
+        zc_dev[which] = d;
+        return d;
+    }
+
     template <typename T>
     hipError_t dalloc(T **p, size_t n) {
         void *q = nullptr;
@@ -1478,19 +1494,20 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     // length (the reference's Nbuffer) or a short call after a shorter one never pays an allocation -- nor, with it, new kernel
     // arguments -- in its steady state (older, smaller buffers are released with the sampler)
     auto grown = [](size_t need, size_t have, size_t unit) { const size_t floor_ = 256 * unit; return std::max(std::max(need, floor_), have * 2); };
-    if (samples && I.smp_cap < (size_t)n_iter * C * Nv) {
+    double *zc_smp = I.device_view(0, samples), *zc_st = I.device_view(1, stats);
+    if (samples && !zc_smp && I.smp_cap < (size_t)n_iter * C * Nv) {
         const size_t cap = grown((size_t)n_iter * C * Nv, I.smp_cap, C * Nv);
         DCHK(I.dalloc(&a.samples, cap));
         I.smp_cap = cap;
     }
-    if (stats && I.stat_cap < (size_t)n_iter * C * 3) {
+    if (stats && !zc_st && I.stat_cap < (size_t)n_iter * C * 3) {
         const size_t cap = grown((size_t)n_iter * C * 3, I.stat_cap, C * 3);
         DCHK(I.dalloc(&a.stats, cap));
         I.stat_cap = cap;
     }
     DevSamplerArgs args = a;
-    if (!samples) args.samples = nullptr;
-    if (!stats) args.stats = nullptr;
+    args.samples = samples ? (zc_smp ? zc_smp : a.samples) : nullptr;
+    args.stats = stats ? (zc_st ? zc_st : a.stats) : nullptr;
     // chain groups [goff[g], goff[g+1]) of the lockstep scheme
     const int G = I.G;
     int goff[5];
@@ -1669,13 +1686,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         // two launches
         const bool timed = c->timing && fused_ev.size() < 16;
         const int fe = I.n_ev - 1 - (int)fused_ev.size();
-        if (timed) DCHK(hipEventRecord(I.ev[fe][0], st));
+        const bool split = f.xsplit < a.C;
+        if (timed && !split) DCHK(hipEventRecord(I.ev[fe][0], st));
         // Two chain groups, each with its own launch per iteration on its own stream: a launch is a chain of dependent steps (slot ->
         // table rows -> tile -> ticket -> settle, ~20 us even for five chains) that leaves most of the GPU idle at its two ends; the two
         // groups' launches fill each other's ends (two 10-chain stars side by side: 24.2 us per iteration each, one 20-chain launch: 27.8).
         // Nothing is shared between the groups' launches except at a swap whose pair straddles the groups: that iteration is ONE launch
         // over all chains on the context stream, with an event each way.  (Same chains bit for bit: the launches' contents are the same.)
-        const bool split = f.xsplit < a.C;
         const int first1 = f.xsplit;
         hipStream_t s1 = I.gst[1];
         long n_split = 0;
@@ -1737,9 +1754,10 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
         }
         if (timed) {  // (read after the call's final synchronisation)
-            DCHK(hipEventRecord(I.ev[fe][1], st));
-            if (n_split == 0) fused_ev.push_back({fe, len});
-            else { g_launches += 2 * n_split + (len - n_split); g_iters += len; }
+            if (!split) {
+                DCHK(hipEventRecord(I.ev[fe][1], st));
+                fused_ev.push_back({fe, len});
+            } else { g_launches += 2 * n_split + (len - n_split); g_iters += len; }
         }
         P = q;
         I.armed_it = it0 + ib;
@@ -1773,8 +1791,8 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     }
     I.parity = P;
     DCHK(hipGetLastError());
-    if (samples) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
-    if (stats) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
+    if (samples && !zc_smp) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
+    if (stats && !zc_st) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
     DCHK(hipStreamSynchronize(st));
     for (const auto &e : fused_ev) {
         float ms = 0;
