@@ -21,8 +21,8 @@ def timed_region(fn, dist=None, sync=None):
             sync()
         if dist is not None:
             dist.barrier()
-        if sync is not None:
-            sync()
+            if sync is not None:
+                sync()
     fence()
     t0 = time.perf_counter()
     out = fn()
