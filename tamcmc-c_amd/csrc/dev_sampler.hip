@@ -1542,6 +1542,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     std::vector<std::pair<int, long>> fused_ev;  // (event pair, launches it brackets) of the fused stretches of this call
     // fused step with two chain groups: the launches of an iteration overlap, so the stretch's elapsed time is not a launch duration;
     // sampled launches of the second group are bracketed on their own stream instead
+    bool s1_open = false;      // the second group's stream still holds launches the context stream has not waited for
     int g_used = 0;            // gev pairs used in this call
     long g_launches = 0, g_iters = 0;  // launches / iterations of the split stretches of this call
     int P = I.parity;
@@ -1750,8 +1751,11 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             q ^= 1;
         }
         if (s1_ahead) {
-            DCHK(hipEventRecord(I.ev_join[1], s1));
-            DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
+            if (ib >= n_iter) s1_open = true;  // the call's last stretch: the host waits for both streams below (no event hop on the GPU)
+            else {
+                DCHK(hipEventRecord(I.ev_join[1], s1));
+                DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
+            }
         }
         if (timed) {  // (read after the call's final synchronisation)
             if (!split) {
@@ -1791,8 +1795,14 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     }
     I.parity = P;
     DCHK(hipGetLastError());
+    if (s1_open && ((samples && !zc_smp) || (stats && !zc_st))) {  // (the copies below read what the second group's launches write)
+        DCHK(hipEventRecord(I.ev_join[1], I.gst[1]));
+        DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
+        s1_open = false;
+    }
     if (samples && !zc_smp) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats && !zc_st) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
+    if (s1_open) DCHK(hipStreamSynchronize(I.gst[1]));
     DCHK(hipStreamSynchronize(st));
     for (const auto &e : fused_ev) {
         float ms = 0;

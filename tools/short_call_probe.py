@@ -33,6 +33,10 @@ for _ in range(calls):
     s.run(n, out=(smp, stt))
     ts.append(time.perf_counter() - t0)
 ts = np.array(ts) * 1e6
+t0 = time.perf_counter()
+for _ in range(200):
+    s.run(0, out=(smp[:0], stt[:0]))
+print(f"an empty call through the Python binding: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us")
 big = pkg.pinned_empty((3000, 20, s.nvars)), pkg.pinned_empty((3000, 20, 3))
 t0 = time.perf_counter()
 s.run(3000, out=big)
