@@ -1676,7 +1676,12 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             sc.gf = (const FusedArgs *)(I.d_argcopy + n1);
         }
         sc.first = 0; sc.cnt = a.C; sc.extra = 1;
+        // does the context stream hold work of this call that the second group's stream has to wait for?  (Every entry point of the
+        // library returns with its streams idle, so a call that starts on carried-over candidates has nothing to wait for: the event
+        // hop would only delay the second group's first launch by 10-30 us.)
+        bool st_has_work = ia > 0;
         if (!(I.armed_it == it0 + ia && I.armed_q == q)) {
+            st_has_work = true;
             // entry: L z of the first two iterations, then the candidates of iteration ia built on the settled chains (state of parity q)
             sc.it = it0 + ia; sc.rec = -1; sc.q = q; sc.flags = ST_LZ; sc.nbr = 0; sc.nlz = nlz2; sc.n_lz_live = 2 * a.C; sc.it_lz = it0 + ia; sc.q_lz = q;
             DCHK(launch_step(c->precision, c->K, nlz2, st, args, f, lf[q], sc));
@@ -1697,7 +1702,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         const int first1 = f.xsplit;
         hipStream_t s1 = I.gst[1];
         long n_split = 0;
-        bool s1_ahead = false, s1_must_wait = true;  // s1 holds launches st has not waited for / s1 has not seen st's latest launches
+        bool s1_ahead = false, s1_must_wait = st_has_work;  // s1 holds launches st has not waited for / s1 has not seen st's latest launches
         auto swap_pair_of = [&](long it) -> int {
             if (!(a.C >= 2 && a.dN_mixing > 0 && (it % a.dN_mixing == 0) && it != 0)) return -1;
             double u, u2;
