@@ -64,7 +64,9 @@ def parse():
                     help="only the timed headline run (no packed / red-giant / MALA / launch-shape / CPU legs): the command profiled under "
                          "rocprofv3 for profiles/, so that the per-kernel averages are those of the headline launches")
     ap.add_argument("--dn-mixing", type=int, default=1, help="parallel-tempering swap attempt every N iterations (reference default 1, config_default.cfg:28)")
-    ap.add_argument("--step-scheme", type=int, default=0, choices=[0, 1], help="device engine: 0 = fused one-launch iterations, 1 = lockstep kernels only")
+    ap.add_argument("--step-scheme", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="device engine: 0 = fused launches (one or two per iteration: automatic), 1 = lockstep kernels only, 2 = fused, one launch per iteration, "
+                         "3 = fused, two chain groups")
     ap.add_argument("--dump-samples", default="", help="every rank saves the samples of its timed region to <this>_rank<r>.npy (multi-rank rehearsal test)")
     a = ap.parse_args()
     a.steps = max(a.steps, 1)
@@ -336,7 +338,7 @@ def main():
         achieved = alg_bytes / k_s / 1e9                     # one launch of the dominant kernel
         agg = value / world * a.chains * 16.0 * a.nx / 1e9   # the whole timed region
         launches_per_iter = k_launches / max(a.steps, 1)
-        fused = (a.engine == "device" and a.sampler == "mh" and a.step_scheme == 0 and prec == pkg.PRECISION_FAST)
+        fused = (a.engine == "device" and a.sampler == "mh" and a.step_scheme != 1 and prec == pkg.PRECISION_FAST)
         pmc = committed_json("r02_pmc_traffic.json") or {}
         pmc_sq = committed_json("r02_pmc_sq.json") or {}
         valu = None

@@ -63,9 +63,11 @@ extern "C" {
 #define TAMCMC_OPT_FD_WINDOWED 5     /* value: 0/1 -- FAST modes: FD gradients from delta tables (only the multiplets a perturbation
                                         changes, on their windows, against the stored base model row); default 1 */
 #define TAMCMC_OPT_WORKGROUP 4       /* value: 256 (four waves share a tile) or 64 (one wave per tile); resets bins per thread */
-#define TAMCMC_OPT_STEP_SCHEME 6     /* device-resident sampler: 0 = automatic (one fused launch per iteration wherever no adaptation
-                                        separates two iterations, lockstep kernels elsewhere), 1 = lockstep kernels only.  Same chains
-                                        bit for bit either way (tests/test_gpu_sampler.py); default 0 */
+#define TAMCMC_OPT_STEP_SCHEME 6     /* device-resident sampler: 0 = automatic (fused launches wherever no adaptation separates two
+                                        iterations -- one launch per iteration, or one per chain group on two streams once a launch no
+                                        longer fits the GPU's resident waves -- lockstep kernels elsewhere), 1 = lockstep kernels only,
+                                        2 = fused with one launch per iteration, 3 = fused with two chain groups whenever there are
+                                        8 chains or more.  Same chains bit for bit in every case (tests/test_gpu_sampler.py); default 0 */
 #define TAMCMC_OPT_ARMM_DENSE_SCAN 7 /* red-giant pre-step: 1 = walk the solver's whole grid like the reference (solver_mm.cpp:340-377)
                                         instead of the pole-structured scan that finds the same cells; default 0 */
 

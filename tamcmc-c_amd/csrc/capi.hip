@@ -86,7 +86,7 @@ int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
         return TAMCMC_OK;
     case TAMCMC_OPT_FD_WINDOWED: c->fd_windowed = value ? 1 : 0; return TAMCMC_OK;
     case TAMCMC_OPT_STEP_SCHEME:
-        if (value != 0 && value != 1) return TAMCMC_ERR_BAD_ARG;
+        if (value < 0 || value > 3) return TAMCMC_ERR_BAD_ARG;
         c->step_scheme = (int)value;
         return TAMCMC_OK;
     case TAMCMC_OPT_ARMM_DENSE_SCAN: c->armm_dense = value ? 1 : 0; return TAMCMC_OK;

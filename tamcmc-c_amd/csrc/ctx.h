@@ -65,7 +65,8 @@ struct tamcmc_hip_ctx {
     int K = 4;      // bins per thread: tile = wgs*K bins
     bool geom_user_set = false;
     int fd_windowed = 1;  // FAST modes: finite differences through delta tables (changed multiplets on their windows only)
-    int step_scheme = 0;  // device sampler: 0 = fused step where possible, 1 = lockstep kernels only
+    int step_scheme = 0;  // device sampler: 0 = fused steps where possible (one or two launches per iteration: automatic), 1 = lockstep kernels only,
+                          // 2 = fused, always one launch per iteration, 3 = fused, two chain groups whenever the chain count allows
     int armm_dense = 0;   // red-giant pre-step: 1 = dense grid walk
     // resident spectrum
     int64_t Nx = 0;

@@ -1483,7 +1483,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     a.partials = c->d_part.p;
     a.tile_bins = tb;
     a.bg = nullptr;
-    const bool use_fused = I.fused_ok && c->step_scheme == 0 && c->wgs == 64 && (c->K == 4 || c->K == 8 || c->K == 16);
+    const bool use_fused = I.fused_ok && c->step_scheme != 1 && c->wgs == 64 && (c->K == 4 || c->K == 8 || c->K == 16);
     const size_t NS = (size_t)I.f.NS;
     if (c->precision == TAMCMC_PRECISION_FAST) {  // background series per (slot, tile): C slots of (B), then 2 x NS slots of (A)
         DCHK(c->d_bg.reserve((C + (use_fused ? 2 * NS : 0)) * (size_t)a.ntiles * 8));
@@ -1692,7 +1692,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         // two launches
         const bool timed = c->timing && fused_ev.size() < 16;
         const int fe = I.n_ev - 1 - (int)fused_ev.size();
-        const bool split = f.xsplit < a.C;
+        // (it pays once one launch no longer fits the GPU's resident waves -- 20 chains x 196 tiles: 27.7 -> 23.9 us, x 782 tiles: 59.8 ->
+        // 49.6 us -- and costs below that: 8 chains x 196 tiles 20.5 -> 23.7 us, 20 chains x 20 tiles 33.5 -> 35.6 us; tools/groups_probe.py)
+        const bool split = f.xsplit < a.C && c->step_scheme != 2 && (c->step_scheme == 3 || (long)a.C * a.ntiles >= 2500);
         if (timed && !split) DCHK(hipEventRecord(I.ev[fe][0], st));
         // Two chain groups, each with its own launch per iteration on its own stream: a launch is a chain of dependent steps (slot ->
         // table rows -> tile -> ticket -> settle, ~20 us even for five chains) that leaves most of the GPU idle at its two ends; the two

@@ -118,13 +118,13 @@ def test_c5_forty_chain_sampler_run(pkg, synth, engine):
 
 def test_headline_shape_two_group_fused_steps_equal_the_lockstep_chain(pkg, synth):
     """C3 (1e5 bins, 20 chains, swaps every iteration): 1500 acquire iterations as fused steps -- two launches per iteration, one per
-    chain group on its own stream, one joint launch whenever the swap pair straddles the groups -- against the lockstep kernels, and
-    against themselves a second time: identical samples and statistics (the groups' launches drift several iterations apart between
+    chain group on its own stream, one joint launch whenever the swap pair straddles the groups -- against the lockstep kernels and
+    against the one-launch fused steps: identical samples and statistics (the groups' launches drift several iterations apart between
     two joint iterations; nothing one group writes may be read by the other before they meet)."""
     star, ctx = _c3_with_spectrum(pkg, synth, 0)
     kw = dict(nchains=20, lambda_temp=1.3, seed=11, engine="device", Nt_learn=(10, 60), periods_learn=(1,), dN_mixing=1, c0=2.0)
     runs = []
-    for scheme in (1, 0, 0):
+    for scheme in (1, 0, 2):      # lockstep | automatic (two groups at this size) | one launch per iteration
         ctx.set_option(pkg.OPT_STEP_SCHEME, scheme)
         s = pkg.Sampler(ctx, star, **kw)
         a1, b1 = s.run(100, stats=True)
