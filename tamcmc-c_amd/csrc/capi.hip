@@ -19,6 +19,16 @@
 
 using tamcmc::StageLayout;
 
+// Measured best tile geometry per arithmetic mode, unless the caller chose one (tools/gpu_probe.py, tools/groups_probe.py).
+// FAST (far field): one wave per tile of 512 bins; spectra below 32768 bins take 256-bin tiles -- on a coarse grid a tile is wide in
+// units of the mode spacing, most multiplets fall into its near field and the tile's own chain of work sets the launch time (1e4 bins,
+// 10-20 chains: 32.6 -> 21.8 us per iteration).  Per-bin loops (STRICT, FAST_DIRECT): four waves per 1024-bin tile.
+static void default_geometry(tamcmc_hip_ctx *c) {
+    if (c->geom_user_set) return;
+    if (c->precision == TAMCMC_PRECISION_FAST) { c->wgs = 64; c->K = (c->Nx > 0 && c->Nx < 32768) ? 4 : 8; }
+    else { c->wgs = 256; c->K = 4; }
+}
+
 extern "C" {
 
 const char *tamcmc_hip_version(void) { return "tamcmc-c_amd 0.1 (gfx950)"; }
@@ -73,10 +83,7 @@ int tamcmc_hip_set_option(tamcmc_hip_ctx *c, int option, int64_t value) {
         if (value != TAMCMC_PRECISION_STRICT && value != TAMCMC_PRECISION_FAST && value != TAMCMC_PRECISION_FAST_DIRECT)
             return TAMCMC_ERR_BAD_ARG;
         c->precision = (int)value;
-        if (!c->geom_user_set) {  // measured best tile geometry per mode (tools/gpu_probe.py)
-            if (value == TAMCMC_PRECISION_FAST) { c->wgs = 64; c->K = 8; }   // far field: one wave per 512-bin tile
-            else { c->wgs = 256; c->K = 4; }                                  // per-bin loops: four waves per 1024-bin tile
-        }
+        default_geometry(c);
         return TAMCMC_OK;
     case TAMCMC_OPT_TIMING: c->timing = value ? 1 : 0; return TAMCMC_OK;
     case TAMCMC_OPT_BINS_PER_THREAD:
@@ -123,6 +130,7 @@ int tamcmc_hip_set_spectrum(tamcmc_hip_ctx *c, const double *x, const double *y,
     HIPCHK(c, hipMemcpyAsync(c->dlogx.p, lx.data(), (size_t)Nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->Nx = Nx;
+    default_geometry(c);
     return TAMCMC_OK;
 }
 

@@ -125,11 +125,12 @@ template <int MODE>
 bool launch_geom_delta(const LoglikeArgs &a, int wgs, int K, int grid, hipStream_t st) {
     if (wgs == 256 && K == 4) hipLaunchKernelGGL((k_loglike<MODE, 256, 4, false, true>), dim3(grid), dim3(256), 0, st, a);
     else if (wgs == 64 && K == 8) hipLaunchKernelGGL((k_loglike<MODE, 64, 8, false, true>), dim3(grid), dim3(64), 0, st, a);
+    else if (wgs == 64 && K == 4) hipLaunchKernelGGL((k_loglike<MODE, 64, 4, false, true>), dim3(grid), dim3(64), 0, st, a);
     else return false;
     return true;
 }
 
-bool delta_geometry(int wgs, int K) { return (wgs == 256 && K == 4) || (wgs == 64 && K == 8); }
+bool delta_geometry(int wgs, int K) { return (wgs == 256 && K == 4) || (wgs == 64 && (K == 8 || K == 4)); }
 
 hipError_t launch_loglike_delta(LoglikeArgs a, int mode, int wgs, int K, hipStream_t st) {
     if (a.B <= 0) return hipSuccess;

@@ -1,5 +1,5 @@
 """Acquire-phase iteration time with one launch per iteration (chain_groups=1) against the default two chain groups, for a few star sizes.
-python tools/groups_probe.py"""
+python tools/groups_probe.py [bins_per_lane]"""
 import os
 import sys
 import time
@@ -13,6 +13,7 @@ import __graft_entry__ as entry
 pkg = entry.load_package()
 from tamcmc_c_amd import synth
 
+kbins = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # bins per lane of the likelihood tile (0 = library default)
 for nx, chains in ((100000, 20), (100000, 8), (10000, 10), (10000, 20), (400000, 20)):
     star = synth.make_c3_star(nx=nx, step=2000.0 / nx)
     ctx = pkg.HipContext(0, precision=pkg.PRECISION_STRICT)
@@ -20,6 +21,8 @@ for nx, chains in ((100000, 20), (100000, 8), (10000, 10), (10000, 20), (400000,
     _, m0, _ = ctx.loglike_params_batch(star.model_id, star.params, star.plength, want_model=True)
     star.set_spectrum_from_model(m0[0], seed=20240301)
     ctx.set_option(pkg.OPT_PRECISION, pkg.PRECISION_FAST)
+    if kbins:
+        ctx.set_option(pkg.OPT_BINS_PER_THREAD, kbins)
     ctx.set_spectrum(star.x, star.y)
     out = []
     for groups in (1, 0):
