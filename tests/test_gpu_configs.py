@@ -139,6 +139,31 @@ def test_headline_shape_two_group_fused_steps_equal_the_lockstep_chain(pkg, synt
     ctx.close()
 
 
+def test_headline_shape_posterior_brackets_the_truth(pkg, synth):
+    """C3 as a sampler, not only as a kernel: 20 tempered chains on the 1e5-bin star, 3000 learning iterations (lockstep kernels with the
+    adaptation), then 24 000 acquire iterations as fused steps.  The coldest chain's posterior (mean / sigma per variable, what
+    tools/bin2txt_params.cpp:165-168 prints) brackets the frequencies the spectrum was drawn from, its acceptance rate has settled near
+    the target (0.234) and the ladder swaps."""
+    star, ctx = _c3_with_spectrum(pkg, synth, 0)
+    s = pkg.Sampler(ctx, star, nchains=20, lambda_temp=1.3, seed=5, engine="device", Nt_learn=(100, 3100), periods_learn=(1,), dN_mixing=1, c0=2.0)
+    s.run(4000, record=False)
+    a0 = s.state()
+    smp, st = s.run(24000, stats=True)
+    a1 = s.state()
+    cold = smp[:, 0, :]
+    mean, std = cold.mean(0), cold.std(0)
+    truth = star.params[star.index_to_relax]
+    fidx = np.array([i for i, k in enumerate(star.index_to_relax) if star.names[k] == "Frequency_l"])
+    z = np.abs(mean[fidx] - truth[fidx]) / std[fidx]
+    assert fidx.size == 56 and np.all(z < 5.5) and np.median(z) < 1.5, z
+    assert np.all(std[fidx] > 1e-4) and np.all(std[fidx] < 2.0)
+    acc = (a1["accepted0"] - a0["accepted0"]) / 24000.0
+    assert 0.08 < acc < 0.5, acc
+    assert 0.05 < (a1["swaps"] - a0["swaps"]) / 24000.0 < 0.95
+    assert np.isfinite(st).all() and st[-2000:, 0, 2].mean() > st[:2000, 0, 2].mean() - 50.0      # no drift away from the mode
+    s.close(); ctx.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
