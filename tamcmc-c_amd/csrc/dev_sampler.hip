@@ -1131,6 +1131,7 @@ struct DevSampler::Impl {
     FdBatch fd;
     DevBuf<unsigned char> fd_block;
     DevBuf<double> fd_part, fd_S, fd_model, fd_bg;
+    DevBuf<double> fused_bg;  // (A): the candidates' background series (see run())
     MalaArgs mala{};
     bool grad_valid = false;
     int prior_class = 0, model_id = 0;
@@ -1164,8 +1165,15 @@ struct DevSampler::Impl {
         if (zc_host[which] == host) return zc_dev[which];
         hipPointerAttribute_t at;
         double *d = nullptr;
-        if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) d = (double *)at.devicePointer;
+        void *dp = nullptr;
+        // (the device address of THIS address: hipHostGetDevicePointer; the attributes only tell that the memory is page-locked)
+        if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dp, const_cast<double *>(host), 0) == hipSuccess && dp)
+            d = (double *)dp;
         else (void)hipGetLastError();  // (pageable memory: not an error for us)
+#ifdef TAMCMC_PROBE
+        if (getenv("TAMCMC_PROBE_ZC")) fprintf(stderr, "device_view: host %p attr.devicePointer %p hipHostGetDevicePointer %p\n", (const void *)host, at.devicePointer, dp);
+#endif
         zc_host[which] = host;
         zc_dev[which] = d;
         return d;
@@ -1197,7 +1205,7 @@ DevSampler::~DevSampler() {
     }
 #endif
     for (void *p : impl->allocs) (void)hipFree(p);
-    impl->fd_block.release(); impl->fd_part.release(); impl->fd_S.release(); impl->fd_model.release(); impl->fd_bg.release();
+    impl->fd_block.release(); impl->fd_part.release(); impl->fd_S.release(); impl->fd_model.release(); impl->fd_bg.release(); impl->fused_bg.release();
     if (impl->h_pack) (void)hipHostFree(impl->h_pack);
     for (int i = 0; i < impl->n_ev; i++) { (void)hipEventDestroy(impl->ev[i][0]); (void)hipEventDestroy(impl->ev[i][1]); }
     for (int i = 0; i < impl->n_gev; i++) { (void)hipEventDestroy(impl->gev[i][0]); (void)hipEventDestroy(impl->gev[i][1]); }
@@ -1485,11 +1493,18 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     a.bg = nullptr;
     const bool use_fused = I.fused_ok && c->step_scheme != 1 && c->wgs == 64 && (c->K == 4 || c->K == 8 || c->K == 16);
     const size_t NS = (size_t)I.f.NS;
-    if (c->precision == TAMCMC_PRECISION_FAST) {  // background series per (slot, tile): C slots of (B), then 2 x NS slots of (A)
-        DCHK(c->d_bg.reserve((C + (use_fused ? 2 * NS : 0)) * (size_t)a.ntiles * 8));
+    I.f.bg = nullptr;
+    if (c->precision == TAMCMC_PRECISION_FAST) {
+        // background series per (slot, tile).  (B): C slots in the context's scratch (rewritten every iteration).  (A): 2 x NS slots of
+        // the sampler's OWN -- the candidates prepared by the last launch of a call are carried over to the next call, and anything else
+        // that runs on the context in between (another sampler, a batched evaluation) rewrites the context's scratch
+        DCHK(c->d_bg.reserve(C * (size_t)a.ntiles * 8));
         a.bg = c->d_bg.p;
+        if (use_fused) {
+            DCHK(I.fused_bg.reserve(2 * NS * (size_t)a.ntiles * 8));
+            I.f.bg = I.fused_bg.p;
+        }
     }
-    I.f.bg = (a.bg && use_fused) ? a.bg + C * (size_t)a.ntiles * 8 : nullptr;
     // record buffers: at least 256 iterations' worth and grown geometrically, so that a caller that records in buffers of a fixed
     // length (the reference's Nbuffer) or a short call after a shorter one never pays an allocation -- nor, with it, new kernel
     // arguments -- in its steady state (older, smaller buffers are released with the sampler)

@@ -90,6 +90,35 @@ def test_fused_steps_are_bitwise_the_lockstep_chain(pkg, oracle, synth, ctx, nch
         assert 0 < state["swaps"] <= state["swap_attempts"]
 
 
+def test_records_written_into_pinned_buffers_equal_the_copied_ones(pkg, oracle, synth, ctx):
+    """run(out=...) with page-locked arrays (pinned_empty / tamcmc_hip_host_alloc): the settle step writes every iteration's sample and
+    statistics straight into the caller's memory; with ordinary arrays the records are kept on the device and copied at the end of the
+    call.  Same records either way, through learning (lockstep kernels) and fused stretches, samples only / statistics only included.
+    The two samplers share one context and take turns on it, with a batched evaluation in between: what a sampler carries from one call
+    to the next (the prepared candidates of the next iteration) must not live in the context's scratch memory."""
+    star = _star_with_data(pkg, oracle, synth)
+    ctx.set_spectrum(star.x, star.y)
+    kw = dict(nchains=9, lambda_temp=1.4, seed=4, Nt_learn=(20, 60), periods_learn=(1,), dN_mixing=1, engine="device")
+    a, b = pkg.Sampler(ctx, star, **kw), pkg.Sampler(ctx, star, **kw)
+    for n in (100, 37, 5):
+        ps, pt = pkg.pinned_empty((n, 9, a.nvars)), pkg.pinned_empty((n, 9, 3))
+        ps[:] = np.nan; pt[:] = np.nan
+        a.run(n, out=(ps, pt))
+        ctx.loglike_params_batch(star.model_id, star.params, star.plength)     # (anything else on the context between two calls:
+        s, t = b.run(n, stats=True)                                            # the candidates a sampler carries over are its own)
+        assert np.array_equal(ps, s) and np.array_equal(pt, t), n
+    ps = pkg.pinned_empty((50, 9, a.nvars))
+    a.run(50, out=(ps, None))
+    s, _ = b.run(50)
+    assert np.array_equal(ps, s)
+    pt = pkg.pinned_empty((50, 9, 3))
+    a.run(50, out=(None, pt))
+    _, t = b.run(50, record=False, stats=True)
+    assert np.array_equal(pt, t)
+    assert np.array_equal(a.state()["vars"], b.state()["vars"])
+    a.close(); b.close()
+
+
 def test_device_engine_learning_adapts(pkg, oracle, synth, ctx):
     star = _star_with_data(pkg, oracle, synth)
     ctx.set_spectrum(star.x, star.y)
