@@ -377,8 +377,8 @@ def main():
                                     "algorithmic_bytes_per_launch": alg_bytes, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                     "launches_per_iteration": launches_per_iter,
                                     "traffic_bytes_per_launch": pmc.get("hbm_bytes_per_launch"),
-                                    "how_measured": ("HIP events on the launching stream around sampled k_step launches of the timed region (every 97th "
-                                                     "iteration, second chain group's stream); from 8 chains on an iteration is two such launches, one per "
+                                    "how_measured": ("HIP events stamped at the start and at the end of sampled k_step launches of the timed region "
+                                                     "(hipExtLaunchKernelGGL; every 97th iteration, second chain group's stream); an iteration is two such launches, one per "
                                                      "chain group, in flight together on two streams (one joint launch when the swap pair straddles "
                                                      "the groups): a launch lasts about one iteration period and the GPU's rate is the sum of the two"
                                                      if fused else "HIP events around sampled k_loglike launches on their stream")},

@@ -25,6 +25,7 @@
 // inter-workgroup synchronisation inside (B) and a launch never overwrites what it still reads in (A).  Both schemes keep the
 // chains' state in the same arrays; a stretch hands over to the next with the parity only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -1084,21 +1085,24 @@ __global__ void __launch_bounds__(64) k_step_wide(const DevSamplerArgs a, const 
 }
 #undef TAMCMC_STEP_BODY
 
+// ev0 / ev1 (optional): events stamped at the kernel's own start and end (hipExtLaunchKernelGGL) -- the duration rocprofv3 reports for a
+// dispatch, without the time the launch waits in its stream
 template <int MODE>
-bool launch_step_k(int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la, const StepCtl &c) {
-    if (K == 4) hipLaunchKernelGGL((k_step<MODE, 4>), dim3(grid), dim3(64), 0, st, a, f, la, c);
-    else if (K == 8) hipLaunchKernelGGL((k_step<MODE, 8>), dim3(grid), dim3(64), 0, st, a, f, la, c);
-    else if (K == 16) hipLaunchKernelGGL((k_step_wide<MODE, 16>), dim3(grid), dim3(64), 0, st, a, f, la, c);
+bool launch_step_k(int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la, const StepCtl &c,
+                   hipEvent_t ev0, hipEvent_t ev1) {
+    if (K == 4) hipExtLaunchKernelGGL((k_step<MODE, 4>), dim3(grid), dim3(64), 0, st, ev0, ev1, 0, a, f, la, c);
+    else if (K == 8) hipExtLaunchKernelGGL((k_step<MODE, 8>), dim3(grid), dim3(64), 0, st, ev0, ev1, 0, a, f, la, c);
+    else if (K == 16) hipExtLaunchKernelGGL((k_step_wide<MODE, 16>), dim3(grid), dim3(64), 0, st, ev0, ev1, 0, a, f, la, c);
     else return false;
     return true;
 }
 hipError_t launch_step(int mode, int K, int grid, hipStream_t st, const DevSamplerArgs &a, const FusedArgs &f, const LoglikeArgs &la,
-                       const StepCtl &c) {
+                       const StepCtl &c, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     if (grid <= 0) return hipSuccess;
     bool ok;
-    if (mode == TAMCMC_PRECISION_FAST) ok = launch_step_k<tile::M_FAST>(K, grid, st, a, f, la, c);
-    else if (mode == TAMCMC_PRECISION_FAST_DIRECT) ok = launch_step_k<tile::M_FAST_DIRECT>(K, grid, st, a, f, la, c);
-    else ok = launch_step_k<tile::M_STRICT>(K, grid, st, a, f, la, c);
+    if (mode == TAMCMC_PRECISION_FAST) ok = launch_step_k<tile::M_FAST>(K, grid, st, a, f, la, c, ev0, ev1);
+    else if (mode == TAMCMC_PRECISION_FAST_DIRECT) ok = launch_step_k<tile::M_FAST_DIRECT>(K, grid, st, a, f, la, c, ev0, ev1);
+    else ok = launch_step_k<tile::M_STRICT>(K, grid, st, a, f, la, c, ev0, ev1);
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }
 
@@ -1728,7 +1732,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             if (A > a.C - 2) A = a.C - 2;
             return A;
         };
-        auto launch_group = [&](int first, int cnt, int A, long i, hipStream_t stream) -> int {
+        auto launch_group = [&](int first, int cnt, int A, long i, hipStream_t stream, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) -> int {
             // every launch also prepares the next iteration's candidates and the L z after that -- the last one too (see armed_it)
             const bool owns_pair = A >= first && A + 1 < first + cnt;
             sc.it = it0 + i; sc.rec = (samples || stats) ? i : (long)-1; sc.q = q;
@@ -1740,7 +1744,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             lq.slot_map = lf[q].slot_map + first;
             lq.partials = lf[q].partials + (size_t)first * a.ntiles * 2;
             if (owns_pair && cnt >= 3) lq.prio_b = A - first;  // this iteration's swap pair leads the launch
-            DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + ntiles_pad * cnt, stream, args, f, lq, sc));
+            DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + ntiles_pad * cnt, stream, args, f, lq, sc, e0, e1));
             return TAMCMC_OK;
         };
         for (long i = ia; i < ib; i++) {
@@ -1754,10 +1758,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
                 int rc = launch_group(0, first1, A, i, st);
                 if (rc) return rc;
                 const bool sample = timed && g_used < I.n_gev && (len >= 97 ? ((i - ia) % 97 == 48) : (i - ia == len / 2));
-                if (sample) DCHK(hipEventRecord(I.gev[g_used][0], s1));
-                rc = launch_group(first1, a.C - first1, A, i, s1);
+                rc = sample ? launch_group(first1, a.C - first1, A, i, s1, I.gev[g_used][0], I.gev[g_used][1]) : launch_group(first1, a.C - first1, A, i, s1);
                 if (rc) return rc;
-                if (sample) { DCHK(hipEventRecord(I.gev[g_used][1], s1)); g_used++; }
+                if (sample) g_used++;
                 s1_ahead = true;
                 n_split++;
             } else {
