@@ -4,7 +4,8 @@
 // step).  Here the whole iteration of ALL tempered chains runs on the GPU; the host only enqueues launches and fetches the recorded
 // samples once per run() call.  Two launch schemes, same chains bit for bit (same Philox streams, same arithmetic, same orders):
 //
-// (A) FUSED STEP, one launch per iteration (k_step) -- used for every stretch of iterations WITHOUT adaptation (the bulk of a run:
+// (A) FUSED STEP, one launch per iteration and set of chains (k_step; all chains, or one launch per chain group on two streams once a
+//     launch outgrows the GPU's resident waves: see run()) -- used for every stretch of iterations WITHOUT adaptation (the bulk of a run:
 //     the reference learns in [Nt_learn[0], Nt_learn[last]) only, config_default.cfg:17-18).  Launch i holds two kinds of 64-lane
 //     workgroups:
 //       * likelihood tiles of iteration i (loglike_tile.h, the hot kernel's body): chain m's proposal of iteration i is table slot
@@ -1670,7 +1671,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         return TAMCMC_OK;
     };
 
-    // ---- (A) fused steps over [ia, ib) (no adaptation inside): one launch per iteration on the context stream
+    // ---- (A) fused steps over [ia, ib) (no adaptation inside): one launch per iteration on the context stream, or two (one per chain group)
     auto fused = [&](long ia, long ib) -> int {
         const FusedArgs &f = I.f;
         const int nbr = 4 * f.NS;                                     // candidate roles, a multiple of 8 (keeps the tiles' XCD mapping)
