@@ -1163,11 +1163,9 @@ struct DevSampler::Impl {
 
     // The caller's record buffer as the device sees it when it is pinned, mapped host memory (tamcmc_hip_host_alloc): the settle step then
     // writes the records straight into it (15 KB per iteration over PCIe, posted) and a call ends without its two device-to-host copies.
-    const void *zc_host[2] = {nullptr, nullptr};
-    double *zc_dev[2] = {nullptr, nullptr};
-    double *device_view(int which, const double *host) {
+    // (asked on every call: an address says nothing about what the caller has freed and allocated since the last one)
+    double *device_view(const double *host) {
         if (!host) return nullptr;
-        if (zc_host[which] == host) return zc_dev[which];
         hipPointerAttribute_t at;
         double *d = nullptr;
         void *dp = nullptr;
@@ -1176,11 +1174,6 @@ struct DevSampler::Impl {
             hipHostGetDevicePointer(&dp, const_cast<double *>(host), 0) == hipSuccess && dp)
             d = (double *)dp;
         else (void)hipGetLastError();  // (pageable memory: not an error for us)
-#ifdef TAMCMC_PROBE
-        if (getenv("TAMCMC_PROBE_ZC")) fprintf(stderr, "device_view: host %p attr.devicePointer %p hipHostGetDevicePointer %p\n", (const void *)host, at.devicePointer, dp);
-#endif
-        zc_host[which] = host;
-        zc_dev[which] = d;
         return d;
     }
 
@@ -1514,7 +1507,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     // length (the reference's Nbuffer) or a short call after a shorter one never pays an allocation -- nor, with it, new kernel
     // arguments -- in its steady state (older, smaller buffers are released with the sampler)
     auto grown = [](size_t need, size_t have, size_t unit) { const size_t floor_ = 256 * unit; return std::max(std::max(need, floor_), have * 2); };
-    double *zc_smp = I.device_view(0, samples), *zc_st = I.device_view(1, stats);
+    double *zc_smp = I.device_view(samples), *zc_st = I.device_view(stats);
     if (samples && !zc_smp && I.smp_cap < (size_t)n_iter * C * Nv) {
         const size_t cap = grown((size_t)n_iter * C * Nv, I.smp_cap, C * Nv);
         DCHK(I.dalloc(&a.samples, cap));
