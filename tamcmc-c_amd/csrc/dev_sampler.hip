@@ -278,53 +278,44 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
     if constexpr (PANELS) {
         if (tid == 0) s_scal[0] = 0.0;  // "not positive definite" flag
         __syncthreads();
-        // one full panel of NB columns (no per-column guards: the LDS reads of a step are requested together)
-        auto panel = [&](const int p0) -> bool {
-            const int c0 = p0 + NB;
-#ifdef TAMCMC_PROBE
-            long pt0 = (long)wall_clock64();
-#endif
-            // (1) the panel's NB x NB diagonal block, by the first NB lanes of wave 0 (lane r = row p0+r in registers; pivots by readlane)
-            if (tid < 64) {
-                double r[NB];
-                const int row = p0 + tid;
+        // (1) a panel's NB x NB diagonal block, by the first NB lanes of wave 0 (lane r = row p0+r in registers; pivots by readlane);
+        //     called by the whole of wave 0
+        auto diag_block = [&](const int p0) __attribute__((always_inline)) {
+            double r[NB];
+            const int row = p0 + tid;
+            static_for<NB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                r[c] = (tid < NB) ? A[(size_t)row * Nv + p0 + c] : 0.0;
+            });
+            bool bad = false;
+            static_for<NB>([&](auto jc) {
+                constexpr int jj = decltype(jc)::value;
+                if (!bad) {  // wave-uniform
+                    const double ajj = lane_value<jj>(r[jj]);
+                    if (!(ajj > 0.0)) bad = true;
+                    else {
+                        const double djj = sqrt(ajj);
+                        if (tid > jj) r[jj] = r[jj] / djj;
+                        else if (tid == jj) r[jj] = djj;
+                        static_for<NB - 1 - jj>([&](auto kc) {
+                            constexpr int kk = jj + 1 + decltype(kc)::value;
+                            const double lk = lane_value<kk>(r[jj]);  // L_(p0+kk),jj
+                            if (tid >= kk) r[kk] = r[kk] - r[jj] * lk;
+                        });
+                    }
+                }
+            });
+            if (bad) { if (tid == 0) s_scal[0] = 1.0; }
+            else if (tid < NB)
                 static_for<NB>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
-                    r[c] = (tid < NB) ? A[(size_t)row * Nv + p0 + c] : 0.0;
+                    if (c <= tid) A[(size_t)row * Nv + p0 + c] = r[c];
                 });
-                bool bad = false;
-                static_for<NB>([&](auto jc) {
-                    constexpr int jj = decltype(jc)::value;
-                    if (!bad) {  // wave-uniform
-                        const double ajj = lane_value<jj>(r[jj]);
-                        if (!(ajj > 0.0)) bad = true;
-                        else {
-                            const double djj = sqrt(ajj);
-                            if (tid > jj) r[jj] = r[jj] / djj;
-                            else if (tid == jj) r[jj] = djj;
-                            static_for<NB - 1 - jj>([&](auto kc) {
-                                constexpr int kk = jj + 1 + decltype(kc)::value;
-                                const double lk = lane_value<kk>(r[jj]);  // L_(p0+kk),jj
-                                if (tid >= kk) r[kk] = r[kk] - r[jj] * lk;
-                            });
-                        }
-                    }
-                });
-                if (bad) { if (tid == 0) s_scal[0] = 1.0; }
-                else if (tid < NB)
-                    static_for<NB>([&](auto cc) {
-                        constexpr int c = decltype(cc)::value;
-                        if (c <= tid) A[(size_t)row * Nv + p0 + c] = r[c];
-                    });
-            }
-            __syncthreads();
-            if (s_scal[0] != 0.0) return false;  // every lane leaves together, L is not touched
-#ifdef TAMCMC_PROBE
-            long pt1 = (long)wall_clock64();
-#endif
-            // (2) the panel's columns below the block, one row per lane: L_i,jj = (A_i,jj - sum_{j' < jj} L_i,j' L_jj,j') / d_jj
+        };
+        // (2) the panel's columns below the block, one row per lane: L_i,jj = (A_i,jj - sum_{j' < jj} L_i,j' L_jj,j') / d_jj
+        auto below_block = [&](const int p0) __attribute__((always_inline)) {
 #pragma clang loop unroll(disable)
-            for (int i = c0 + tid; i < Nv; i += TB) {
+            for (int i = p0 + NB + tid; i < Nv; i += TB) {
                 double li[NB], Ld[NB][NB];  // the row's panel entries and the diagonal block: every LDS read is requested before the first use
                 static_for<NB>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
@@ -347,26 +338,27 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
                     A[(size_t)i * Nv + p0 + c] = li[c];
                 });
             }
-            __syncthreads();
-#ifdef TAMCMC_PROBE
-            long pt2 = (long)wall_clock64();
-#endif
-            // (3) the panel's NB columns applied to the trailing block (rows i >= c0, columns c0..i), lanes as a 16 x 16 grid
+        };
+        // (3) the panel's NB columns applied to columns kb..ke-1 of the trailing block (rows i >= kb, columns <= i); the calling lanes
+        //     form an RS x CS grid (ri, rk)
+        auto trailing = [&](const int p0, const int kb, const int ke, const int ri, const int rk, auto rs_c, auto cs_c) __attribute__((always_inline)) {
+            constexpr int RS = decltype(rs_c)::value, CS = decltype(cs_c)::value;
 #pragma clang loop unroll(disable)
-            for (int i = c0 + ti; i < Nv; i += 16) {
+            for (int i = kb + ri; i < Nv; i += RS) {
                 double li[NB];
                 static_for<NB>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
                     li[c] = A[(size_t)i * Nv + p0 + c];
                 });
-                int k = c0 + tk;
+                const int kend = i < ke - 1 ? i : ke - 1;  // last column of the row
+                int k = kb + rk;
 #pragma clang loop unroll(disable)
-                for (; k + 16 <= i; k += 32) {  // two columns per trip: their LDS reads are in flight together (one wave per SIMD here)
-                    double v0 = A[(size_t)i * Nv + k], v1 = A[(size_t)i * Nv + k + 16], l0[NB], l1[NB];
+                for (; k + CS <= kend; k += 2 * CS) {  // two columns per trip: their LDS reads are in flight together (one wave per SIMD here)
+                    double v0 = A[(size_t)i * Nv + k], v1 = A[(size_t)i * Nv + k + CS], l0[NB], l1[NB];
                     static_for<NB>([&](auto cc) {
                         constexpr int c = decltype(cc)::value;
                         l0[c] = A[(size_t)k * Nv + p0 + c];
-                        l1[c] = A[(size_t)(k + 16) * Nv + p0 + c];
+                        l1[c] = A[(size_t)(k + CS) * Nv + p0 + c];
                     });
                     static_for<NB>([&](auto cc) {
                         constexpr int c = decltype(cc)::value;
@@ -374,9 +366,9 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
                         v1 = v1 - li[c] * l1[c];
                     });
                     A[(size_t)i * Nv + k] = v0;
-                    A[(size_t)i * Nv + k + 16] = v1;
+                    A[(size_t)i * Nv + k + CS] = v1;
                 }
-                if (k <= i) {
+                if (k <= kend) {
                     double v = A[(size_t)i * Nv + k];
                     static_for<NB>([&](auto cc) {
                         constexpr int c = decltype(cc)::value;
@@ -385,6 +377,32 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
                     A[(size_t)i * Nv + k] = v;
                 }
             }
+        };
+        // Schedule: the next panel's diagonal block (the serial sqrt -> divide chain) is factored by wave 0 WHILE waves 1-3 apply the
+        // current panel to the rest of the trailing block; only the next panel's own NB columns are updated ahead of it by all lanes.
+#pragma clang loop unroll(disable)
+        for (int p = -NB;;) {  // p: the panel being applied (none yet on the first trip, which only factors block 0)
+            const int c0 = p + NB;
+#ifdef TAMCMC_PROBE
+            long pt0 = (long)wall_clock64(), pt1 = pt0;
+#endif
+            if (p >= 0) {
+                below_block(p);
+                __syncthreads();
+#ifdef TAMCMC_PROBE
+                pt1 = (long)wall_clock64();
+#endif
+                trailing(p, c0, c0 + NB, tid >> 3, tid & 7, std::integral_constant<int, TB / 8>{}, std::integral_constant<int, 8>{});
+                __syncthreads();
+            }
+            j0 = c0;
+            if (c0 + NB > Nv) break;  // fewer than NB columns left: the slice above was the whole trailing block
+#ifdef TAMCMC_PROBE
+            long pt2 = (long)wall_clock64();
+#endif
+            if (tid < 64) diag_block(c0);
+            else if (p >= 0)
+                trailing(p, c0 + NB, Nv, (tid - 64) >> 4, tid & 15, std::integral_constant<int, (TB - 64) / 16>{}, std::integral_constant<int, 16>{});
             __syncthreads();
 #ifdef TAMCMC_PROBE
             if (m == 0 && tid == 0) {
@@ -392,10 +410,9 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
                 a.counters[4] += pt1 - pt0; a.counters[5] += pt2 - pt1; a.counters[6] += pt3 - pt2; a.counters[7] += 1;
             }
 #endif
-            return true;
-        };
-#pragma clang loop unroll(disable)
-        for (; j0 + NB <= Nv && pd; j0 += NB) pd = panel(j0);
+            if (s_scal[0] != 0.0) { pd = false; break; }  // every lane leaves together, L is not touched
+            p = c0;
+        }
     }
     // the columns the panels leave (fewer than NB; all of them for wide proposals, whose work matrix is in device memory): one per step
 #pragma clang loop unroll(disable)
