@@ -1215,7 +1215,7 @@ DevSampler::~DevSampler() {
         long h[8];
         (void)hipMemcpy(h, impl->a.counters, sizeof h, hipMemcpyDeviceToHost);
         if (h[7] > 0)
-            fprintf(stderr, "Cholesky panels of chain 0 (us per panel): diagonal block %.2f | columns below %.2f | trailing update %.2f  (%ld panels)\n",
+            fprintf(stderr, "Cholesky panels of chain 0 (us per panel): columns below %.2f | next panel's columns %.2f | next diagonal block beside the rest of the trailing update %.2f  (%ld panels)\n",
                     0.01 * h[4] / h[7], 0.01 * h[5] / h[7], 0.01 * h[6] / h[7], h[7]);
     }
 #endif
