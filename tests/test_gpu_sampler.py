@@ -350,6 +350,42 @@ def test_engine_matrix_of_awkward_shapes(pkg, oracle, synth, nchains, nx, dn, wg
     h.close(); d.close(); c.close()
 
 
+@pytest.mark.parametrize("n_free", [3, 7, 8, 9, 15, 16, 17, 21, 24, 25, 31, 32, 33, 47])
+def test_learning_factor_at_every_panel_remainder(pkg, oracle, synth, n_free):
+    """The device engine factors (Sigma + eps)sigma in panels of 8 columns with the next panel's diagonal block taken ahead; the host engine
+    factors column by column.  Same operations per element, so with adaptation in every iteration the two engines must stay on one
+    trajectory whatever the number of free variables leaves after the last full panel (0, 1, 7 columns; fewer than one panel; one
+    panel exactly)."""
+    if n_free <= 21:
+        star = _star_with_data(pkg, oracle, synth, nx=1500, seed=n_free)
+    else:
+        star = synth.make_c3_star(nx=3000, step=0.7)
+        _, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+        star.set_spectrum_from_model(m0, n_free)
+    for i in star.index_to_relax[n_free:]:  # freeze the rest (prior switch 0 = Fix)
+        star.relax[i] = 0
+        star.priors_switch[i] = 0
+        star.priors[:, i] = -9999.0
+    assert star.nvars == n_free
+    c = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    c.set_spectrum(star.x, star.y)
+    kw = dict(nchains=3, lambda_temp=1.5, seed=40 + n_free, Nt_learn=(4, 10**6), periods_learn=(1,), c0=2.0)
+    h = pkg.Sampler(c, star, engine="host", **kw)
+    d = pkg.Sampler(c, star, engine="device", **kw)
+    n = 60
+    sh, _ = h.run(n, stats=True)
+    sd, _ = d.run(n, stats=True)
+    same = np.all(np.isclose(sh, sd, rtol=1e-8, atol=1e-11), axis=(1, 2))
+    first_div = n if same.all() else int(np.argmin(same))
+    assert first_div >= 40, f"engines diverge at iteration {first_div}"
+    if first_div == n:
+        for m in range(3):
+            (mh, ch), (md, cd) = h.get_proposal(m), d.get_proposal(m)
+            assert np.allclose(mh, md, rtol=1e-9, atol=1e-12) and np.allclose(ch, cd, rtol=1e-7, atol=1e-14)
+    assert (sd[1:, 0] != sd[:-1, 0]).any()  # the adapted proposal moves the chain
+    h.close(); d.close(); c.close()
+
+
 def test_context_and_samplers_can_go_in_any_order(pkg, oracle, synth):
     """A sampler borrows its context (stream, device buffers).  tamcmc_hip_destroy with samplers still alive only marks the context;
     the last tamcmc_sampler_destroy releases it -- so garbage collection in arbitrary order cannot touch freed memory."""
