@@ -61,13 +61,17 @@ __device__ __forceinline__ double lane_value(double x) {
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a compile-time constant in every copy of its body,
 // so that small register arrays indexed by it stay in registers (`#pragma unroll` is a request the optimiser may turn down)
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
+// (the body's call is inlined whatever the caller's size: left as a call, the arrays its lambda captures by reference live in scratch)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_from(F &f) {
+    if constexpr (I < N) {
+        [[clang::always_inline]] f(std::integral_constant<int, I>{});
+        static_for_from<I + 1, N>(f);
+    }
 }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
+    static_for_from<0, N>(f);
 }
 
 __global__ void k_fill_poly(mt::PolyTab *t) {
@@ -114,7 +118,7 @@ __device__ __forceinline__ AcceptOut mh_outcome(const AT &a, int j, long itp, do
 
 // (B): computed by a whole 256-thread workgroup; every workgroup that needs chain j's outcome (the chain's own workgroup and, in a
 // swap step, its partner's) recomputes it from the same inputs -> identical results.
-__device__ void accept_result(const DevSamplerArgs &a, int j, long itp, int P, double *s_red, AcceptOut *s_out) {
+__device__ __forceinline__ void accept_result(const DevSamplerArgs &a, int j, long itp, int P, double *s_red, AcceptOut *s_out) {
     const int tid = threadIdx.x;
     // same reduction order as k_finalize (kernels.hip): strided per-thread sums, shuffle tree, waves in order
     double s1 = 0, s2 = 0;
@@ -226,15 +230,43 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
     // read and written once); lanes as a 16 x 16 grid over (row, column): no index arithmetic per element, 128-byte runs per row
     const int gi = tid >> 4, gk = tid & 15;
     n2 = 0;
-    for (int i = gi; i < Nv; i += 16) {
-        const double di = d[i];
-        for (int j = gk; j < Nv; j += 16) {
-            const size_t e = (size_t)i * Nv + j;
-            const double c = cov[e];
-            const double v = c + g * (di * d[j] - c);
-            cov[e] = v;
-            A[e] = v;
-            n2 += v * v;
+    constexpr int CB = 8;  // columns of a lane per batch: two rows x CB device-memory reads are in flight before the first use
+#pragma clang loop unroll(disable)
+    for (int i = gi; i < Nv; i += 32) {
+        const int i2 = i + 16;
+        const bool two = i2 < Nv;
+        const double di = d[i], di2 = two ? d[i2] : 0.0;
+#pragma clang loop unroll(disable)
+        for (int jb = gk; jb < Nv; jb += 16 * CB) {
+            double c0[CB], c1[CB];
+            static_for<CB>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int j = jb + 16 * q;
+                c0[q] = (j < Nv) ? cov[(size_t)i * Nv + j] : 0.0;
+                c1[q] = (two && j < Nv) ? cov[(size_t)i2 * Nv + j] : 0.0;
+            });
+            static_for<CB>([&](auto qc) {  // row i (the sum of squares keeps the element order of a plain row-by-row sweep per lane)
+                constexpr int q = decltype(qc)::value;
+                const int j = jb + 16 * q;
+                if (j < Nv) {
+                    const size_t e = (size_t)i * Nv + j;
+                    const double v = c0[q] + g * (di * d[j] - c0[q]);
+                    cov[e] = v;
+                    A[e] = v;
+                    n2 += v * v;
+                }
+            });
+            static_for<CB>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int j = jb + 16 * q;
+                if (two && j < Nv) {
+                    const size_t e = (size_t)i2 * Nv + j;
+                    const double v = c1[q] + g * (di2 * d[j] - c1[q]);
+                    cov[e] = v;
+                    A[e] = v;
+                    n2 += v * v;
+                }
+            });
         }
     }
 #ifdef TAMCMC_PROBE
@@ -441,7 +473,7 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
             for (int i = gk; i < Nv; i += 16) LT[(size_t)k * Nv + i] = (k <= i) ? A[(size_t)i * Nv + k] : 0.0;
     __syncthreads();
 }
-__device__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const double *vars, double Pm, double *A, double *d, double *s_red,
+__device__ __forceinline__ void adapt_chain(const DevSamplerArgs &a, int m, long itp, const double *vars, double Pm, double *A, double *d, double *s_red,
                             double *s_scal) {
     typedef double __attribute__((address_space(3))) *lds_dp_t;
     typedef double __attribute__((address_space(1))) *dev_dp_t;
@@ -494,7 +526,7 @@ __host__ __device__ inline bool is_rgb_model(int id) { return id == TAMCMC_MODEL
 // Proposal of iteration `it` for `chain` from the state in LDS (s_vars/s_params): x' = x + L z (MALA.cpp:348-355), L =
 // chol((Sigma+eps2) sigma) stored transposed, same Philox streams as the host engine; log-prior; params' -> multiplet table
 // written into slot `slot` of the likelihood kernel's input block.  Ends without a barrier.  (B): 256 threads.
-__device__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int chain, long it, int slot, double *pv, double *pp,
+__device__ __forceinline__ void propose_common(const DevSamplerArgs &a, const UnpackLds &U, int chain, long it, int slot, double *pv, double *pp,
                                double *logPr_out, int *status_out, double *s_vars, double *s_params, double *s_z, const double *lz = nullptr,
                                const rgb::Slice *rs = nullptr, int rb = 0) {
     const int Np = a.desc.Np, Nv = a.Nv, tid = threadIdx.x;
