@@ -68,6 +68,33 @@ int tamcmc_sampler_create(tamcmc_sampler **s, tamcmc_hip_ctx *ctx, const tamcmc_
 void tamcmc_sampler_destroy(tamcmc_sampler *s);
 int64_t tamcmc_sampler_nvars(const tamcmc_sampler *s);
 
+/* ---- size limits of the sampler (the reference factors any size with Eigen's LLT, MALA.cpp:339-369, and caps Nchains at 24, :580-587) ----
+ *   quantity                       limit                 beyond it
+ *   Nchains                        <= 64                 tamcmc_sampler_create returns TAMCMC_ERR_BAD_ARG
+ *   Harvey terms                   <= TAMCMC_MAX_HARVEY  TAMCMC_ERR_BAD_ARG
+ *   Nvars, device engine:          none                  the adaptation's work matrix (Nvars^2 + Nvars doubles: covariance update, Cholesky
+ *     adaptation workspace in LDS  while (Nvars^2 + Nvars) 8 B + (Nparams + 2 Nvars) 8 B + 4.3 KB <= 150 KB, i.e. Nvars <~ 135
+ *                                                        factor) moves from LDS to a per-chain block of device memory -- same operations
+ *                                                        in the same order, same factor bit for bit, several times slower per learning
+ *                                                        iteration (TAMCMC_INFO_ADAPT_IN_LDS = 0); the Langevin engine's test kernel: Nvars <~ 139
+ *   Nparams + 2 Nvars, device      <= 971                the fused one-launch iteration borrows the likelihood tile's 12 KB of LDS for its
+ *     engine, fused step                                 candidate roles; longer vectors run every iteration on the lockstep kernels
+ *                                                        (TAMCMC_INFO_FUSED_AVAILABLE = 0) -- same chains bit for bit
+ *   red-giant models (ids 25/27)   lockstep kernels only; no Langevin step (use_drift = 1 -> TAMCMC_ERR_BAD_MODEL)
+ * The host-driven engine has no size-dependent branches (host memory, column Cholesky).
+ * tamcmc_sampler_get_info reports which side of each limit a sampler is on and how many iterations each scheme has run. */
+#define TAMCMC_INFO_ENGINE 0          /* 0 host-driven, 1 device-resident */
+#define TAMCMC_INFO_NVARS 1
+#define TAMCMC_INFO_NPARAMS 2
+#define TAMCMC_INFO_NCHAINS 3
+#define TAMCMC_INFO_ADAPT_IN_LDS 4    /* device engine: 1 = adaptation workspace in LDS, 0 = in device memory; -1 host engine */
+#define TAMCMC_INFO_FUSED_AVAILABLE 5 /* device engine: the fused one-launch iteration can be used for this star */
+#define TAMCMC_INFO_CHAIN_GROUPS 6
+#define TAMCMC_INFO_ITER_FUSED 7      /* iterations run as fused launches since creation */
+#define TAMCMC_INFO_ITER_LOCKSTEP 8   /* iterations run by the lockstep kernels (adaptation, long vectors, red giants, Langevin) */
+#define TAMCMC_SAMPLER_INFO_N 9
+int tamcmc_sampler_get_info(const tamcmc_sampler *s, int64_t *info, int32_t n);
+
 /* Advances all chains by n_iter iterations.  Optional outputs, one record per iteration after the swap step
  * (what update_buffer_params / update_buffer_stat_criteria record, MALA.cpp:708-710):
  *   samples : [n_iter x Nchains x Nvars]      stats : [n_iter x Nchains x 3] = logL (tempered), logPrior, logPosterior */

@@ -11,6 +11,7 @@
  *   parallel_tempering                      MALA.cpp:397-461   adjacent pair, tempered likelihoods; the line-444 quirk selectable
  *   the loop body of MALA::execute          MALA.cpp:645-703   propose / generate_model / accept per chain, learning test, swap
  *   Model_def::generate_model               model_def.cpp:466-482  (on top of orc_call_prior / orc_call_model / orc_call_likelihood)
+ *   the Langevin step (use_drift = 1)       no reference counterpart (stubs at MALA.cpp:321-337, fatal at :496-500): second half of this file
  *
  * Pinning status: the reference holds no stored numbers for a sampler step (its RNG cannot be seeded); these functions are a
  * statement-by-statement reading of the cited lines and are checked by hand-computed known answers (tests/test_oracle_sampler.py).
@@ -22,6 +23,8 @@
 #include <string.h>
 
 #include "tamcmc_oracle.h"
+
+#define ORC_PI_L 3.141592653589793238462643383279502884L
 
 /* ---- MALA.cpp:135-151 ---- */
 long double orc_p1_fct(long double x, long double epsilon1, long double A1) {
@@ -239,5 +242,199 @@ int orc_sampler_iteration(const orc_sampler_star *S, long i, int learn, int do_s
         double Pswap;
         *swapped = orc_parallel_tempering(logL, logPrior, logPost, vars, params, moved, Pmove, S->Tcoefs, Nv, Np, ind_A, u_swap, literal_444, &Pswap);
     }
+    return fatal ? -1 : 0;
+}
+
+/* =====================================================================================================================================
+ * Langevin step (use_drift = 1).  NO REFERENCE COUNTERPART: MALA::D_MALA returns zeros (MALA.cpp:321-328), multinormal_logpdf returns 0
+ * (:330-337) and use_drift = 1 is fatal (:496-500); the acceptance ratio they were meant to feed is written at :515 as
+ * exp(logPost' - logPost + logproba_prop - logproba_cur).  What follows restates the step the north star names -- finite-difference
+ * gradient of the reference log-posterior -> preconditioned drift -> Gaussian proposal -> Metropolis-Hastings ratio with BOTH proposal
+ * densities -- from its textbook definition (Roberts & Tweedie 1996; truncated drift: Atchade 2006, the paper MALA.cpp:18 cites),
+ * independently of the product: the densities are full multivariate-normal log-densities evaluated by Gaussian elimination with pivoting
+ * in long double (no Cholesky factor, no dropped normalisation), the gradient is recomputed from the position at every use (the product
+ * carries it along and re-tempers it on swaps), and the likelihood differences are taken term by term in long double.
+ *     M_m        = (covarmat_m + epsilon2 I) sigma_m                      the proposal covariance of MALA.cpp:348
+ *     grad(x)    = forward differences (steps h) of  logL(x)/T_m + logPrior(x)
+ *     drift_m(x) = (1/2) M_m grad(x) min(1, delta/|grad(x)|)              (no truncation for delta <= 0)
+ *     x'         = x + drift_m(x) + chol(M_m) z
+ *     r          = min(1, exp(logPost(x') - logPost(x) + log N(x; x' + drift_m(x'), M_m) - log N(x'; x + drift_m(x), M_m)))
+ * Parity status: unpinned by the reference (it holds no such step); pinned by closed-form known answers in tests/test_oracle_sampler.py
+ * (a Gaussian target sampled exactly by the unadjusted step, detailed balance of the kernel on a grid).
+ * ===================================================================================================================================== */
+
+/* log N(v; mean, M) of an n-variate normal, M symmetric positive definite (row-major).  Gaussian elimination with partial pivoting on
+ * [M | v - mean] in long double: quadratic form from the solution, log det from the pivots.  Returns NaN for a singular matrix. */
+long double orc_mvn_logpdf(const double *v, const double *mean, const double *M, long n) {
+    long double *A = (long double *)malloc((size_t)(n * (n + 1)) * sizeof(long double));
+    long double *d = (long double *)malloc((size_t)n * sizeof(long double));
+    for (long i = 0; i < n; i++) {
+        for (long j = 0; j < n; j++) A[i * (n + 1) + j] = M[i * n + j];
+        d[i] = (long double)v[i] - (long double)mean[i];
+        A[i * (n + 1) + n] = d[i];
+    }
+    long double logdet = 0;
+    int bad = 0;
+    for (long k = 0; k < n && !bad; k++) {
+        long piv = k;
+        for (long i = k + 1; i < n; i++)
+            if (fabsl(A[i * (n + 1) + k]) > fabsl(A[piv * (n + 1) + k])) piv = i;
+        if (piv != k)
+            for (long j = 0; j <= n; j++) { const long double t = A[k * (n + 1) + j]; A[k * (n + 1) + j] = A[piv * (n + 1) + j]; A[piv * (n + 1) + j] = t; }
+        const long double p = A[k * (n + 1) + k];
+        if (!(fabsl(p) > 0)) { bad = 1; break; }
+        logdet += logl(fabsl(p));   /* |det| = prod |pivots|; M is positive definite, so det > 0 */
+        for (long i = k + 1; i < n; i++) {
+            const long double f = A[i * (n + 1) + k] / p;
+            for (long j = k; j <= n; j++) A[i * (n + 1) + j] -= f * A[k * (n + 1) + j];
+        }
+    }
+    long double q = 0;
+    if (!bad) {
+        for (long i = n - 1; i >= 0; i--) {   /* back substitution: A[i][n] <- (M^-1 d)[i] */
+            long double s = A[i * (n + 1) + n];
+            for (long j = i + 1; j < n; j++) s -= A[i * (n + 1) + j] * A[j * (n + 1) + n];
+            A[i * (n + 1) + n] = s / A[i * (n + 1) + i];
+        }
+        for (long i = 0; i < n; i++) q += d[i] * A[i * (n + 1) + n];
+    }
+    free(A); free(d);
+    if (bad) return NAN;
+    return -0.5L * q - 0.5L * logdet - 0.5L * (long double)n * logl(2 * ORC_PI_L);
+}
+
+/* Forward-difference gradient of the tempered log-posterior at `params` (steps h[k] on variable k = parameter index_to_relax[k]):
+ *   likelihood share  (logL(theta + h e_k) - logL(theta)) / h_applied / T with logL = -p sum_i (y_i / M_i + ln M_i) (likelihoods.cpp:17-28),
+ *                     the difference of the two sums taken bin by bin in long double (a difference of two rounded ~Nx-term sums would
+ *                     carry ~1e-16 Nx |logL| / h of noise);
+ *   prior share       forward difference of call_prior; when theta + h e_k leaves the prior's support, the backward difference; when both
+ *                     neighbours do, zero (the convention of the product's gradient, stated in include/tamcmc_sampler.h);
+ *   a component that is not finite (table failure at the perturbed point) is zero.
+ * grad = both shares, gradP = the prior's share alone.  Returns the model status of the base point. */
+int orc_fd_gradient_posterior(const orc_sampler_star *S, const double *params, double Tcoef, const double *h, double *grad, double *gradP) {
+    const long Nv = S->Nvars, Np = S->Nparams, Nx = S->Nx;
+    const long p = (long)S->likelihood_params;
+    double *M0 = (double *)malloc((size_t)Nx * sizeof(double));
+    const int st0 = orc_call_model(S->model_id, params, S->plength, S->x, Nx, M0);
+    const double pr0 = orc_call_prior(S->prior_class, params, S->plength, S->priors, S->priors_switch, S->extra_priors);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long k = 0; k < Nv; k++) {
+        double *q = (double *)malloc((size_t)Np * sizeof(double)), *M1 = (double *)malloc((size_t)Nx * sizeof(double));
+        memcpy(q, params, (size_t)Np * sizeof(double));
+        const long j = S->index_to_relax[k];
+        volatile double xp = params[j] + h[k];
+        const double happ = xp - params[j];
+        q[j] = xp;
+        const int st1 = orc_call_model(S->model_id, q, S->plength, S->x, Nx, M1);
+        double gl = NAN;
+        if (st0 == ORC_OK && st1 == ORC_OK) {
+            long double acc = 0;
+            for (long i = 0; i < Nx; i++) {
+                const long double m0 = M0[i], m1 = M1[i], dm = m1 - m0;
+                acc += (long double)S->y[i] * (-dm) / (m0 * m1) + log1pl(dm / m0);   /* y/M1 - y/M0 + ln M1 - ln M0 */
+            }
+            gl = (double)((-(long double)p * acc) / Tcoef / happ);
+        }
+        if (!isfinite(gl)) gl = 0.0;
+        const double prp = orc_call_prior(S->prior_class, q, S->plength, S->priors, S->priors_switch, S->extra_priors);
+        double gp;
+        if (isfinite(prp)) gp = (prp - pr0) / happ;
+        else {
+            q[j] = params[j] - h[k];
+            const double prm = orc_call_prior(S->prior_class, q, S->plength, S->priors, S->priors_switch, S->extra_priors);
+            gp = isfinite(prm) ? (pr0 - prm) / happ : 0.0;
+        }
+        const double g = gl + gp;
+        grad[k] = isfinite(g) ? g : 0.0;
+        gradP[k] = isfinite(g) ? gp : 0.0;
+        free(q); free(M1);
+    }
+    free(M0);
+    return st0;
+}
+
+/* drift = (1/2) sigma (covarmat + epsilon2 I) grad min(1, delta / |grad|)   (what D_MALA, MALA.cpp:321-328, was to return) */
+void orc_langevin_drift(const double *covarmat, double sigma, double epsi2, double delta, const double *grad, long Nvars, double *drift) {
+    long double n2 = 0;
+    for (long k = 0; k < Nvars; k++) n2 += (long double)grad[k] * grad[k];
+    const long double nrm = sqrtl(n2);
+    long double scale = 1;
+    if (delta > 0 && nrm > delta) scale = delta / nrm;
+    for (long i = 0; i < Nvars; i++) {
+        long double acc = 0;
+        for (long j = 0; j < Nvars; j++) acc += ((long double)covarmat[i * Nvars + j] + (i == j ? (long double)epsi2 : 0.0L)) * grad[j];
+        drift[i] = isfinite((double)nrm) ? (double)(0.5L * sigma * scale * acc) : 0.0;
+    }
+}
+
+/* One pass of the sampler's loop body (the structure of MALA.cpp:645-703) with the Langevin proposal.  Arguments as orc_sampler_iteration, plus:
+ * fd_step_rel (steps h_k = fd_step_rel max(|mu_0k|, 1e-3) from chain 0's running mean BEFORE this iteration's adaptation -- the product's
+ * rule, include/tamcmc_sampler.h), delta (drift truncation), diag (may be NULL) [Nchains x 4] = log q(x'|x), log q(x|x'), |drift(x)|, |drift(x')|,
+ * chain_mask (may be NULL) [Nchains]: only the flagged chains are advanced (a check of a few chains of a large ladder; the caller flags
+ * the swap pair, and compares the flagged chains only). */
+int orc_langevin_iteration(const orc_sampler_star *S, long i, int learn, int do_swap, int ind_A, double u_swap, int literal_444, const double *z,
+                           const double *u_mh, double fd_step_rel, double delta, double *params, double *vars, double *logL, double *logPrior,
+                           double *logPost, int *moved, double *Pmove, double *mu, double *covarmat, double *sigma, int *swapped,
+                           double *prop_vars, double *prop_stats, double *diag, const int *chain_mask) {
+    const long C = S->Nchains, Nv = S->Nvars, Np = S->Nparams;
+    const long double gamma = (long double)S->c0 / (1. + i);
+    double *h = (double *)malloc((size_t)Nv * sizeof(double));
+    for (long k = 0; k < Nv; k++) h[k] = fd_step_rel * fmax(fabs(mu[k]), 1e-3);
+    int fatal = 0;
+    for (long m = 0; m < C; m++) {   /* serial over chains: the gradient is parallel over variables */
+        if (chain_mask && !chain_mask[m]) continue;
+        double *g = (double *)malloc((size_t)Nv * sizeof(double)), *gp = (double *)malloc((size_t)Nv * sizeof(double));
+        double *d0 = (double *)malloc((size_t)Nv * sizeof(double)), *d1 = (double *)malloc((size_t)Nv * sizeof(double));
+        double *mean = (double *)malloc((size_t)Nv * sizeof(double)), *v_new = (double *)malloc((size_t)Nv * sizeof(double));
+        double *p_new = (double *)malloc((size_t)Np * sizeof(double)), *model = (double *)malloc((size_t)S->Nx * sizeof(double));
+        double *Mm = (double *)malloc((size_t)(Nv * Nv) * sizeof(double));
+        const double *cov = covarmat + (size_t)m * Nv * Nv, *x = vars + (size_t)m * Nv;
+        for (long a = 0; a < Nv; a++)
+            for (long b = 0; b < Nv; b++) Mm[a * Nv + b] = (cov[a * Nv + b] + (a == b ? S->epsi2 : 0.0)) * sigma[m];
+        /* drift at the current position */
+        orc_fd_gradient_posterior(S, params + (size_t)m * Np, S->Tcoefs[m], h, g, gp);
+        orc_langevin_drift(cov, sigma[m], S->epsi2, delta, g, Nv, d0);
+        /* x' = x + drift + L z */
+        for (long k = 0; k < Nv; k++) mean[k] = x[k] + d0[k];
+        orc_new_prop_values(cov, sigma[m], S->epsi2, mean, z + (size_t)m * Nv, Nv, v_new, NULL);
+        memcpy(p_new, params + (size_t)m * Np, (size_t)Np * sizeof(double));
+        for (long k = 0; k < Nv; k++) p_new[S->index_to_relax[k]] = v_new[k];
+        double l, pr, po, r;
+        orc_generate_model(S, p_new, S->Tcoefs[m], S->init_logL[m], model, &l, &pr, &po);
+        if (prop_vars) memcpy(prop_vars + (size_t)m * Nv, v_new, (size_t)Nv * sizeof(double));
+        if (prop_stats) { prop_stats[3 * m] = l; prop_stats[3 * m + 1] = pr; prop_stats[3 * m + 2] = po; }
+        long double lq_fwd = 0, lq_rev = 0;
+        double nd1 = 0;
+        if (isnan(l) == 0 && po != -INFINITY) {
+            orc_fd_gradient_posterior(S, p_new, S->Tcoefs[m], h, g, gp);
+            orc_langevin_drift(cov, sigma[m], S->epsi2, delta, g, Nv, d1);
+            lq_fwd = orc_mvn_logpdf(v_new, mean, Mm, Nv);                 /* log q(x'|x) = log N(x'; x + drift(x), M) */
+            for (long k = 0; k < Nv; k++) mean[k] = v_new[k] + d1[k];
+            lq_rev = orc_mvn_logpdf(x, mean, Mm, Nv);                     /* log q(x|x') = log N(x; x' + drift(x'), M) */
+            nd1 = norm2(d1, Nv);
+            const double e = exp((double)((long double)po - (long double)logPost[m] + lq_rev - lq_fwd));
+            r = isnan(e) ? 0.0 : (e < 1. ? e : 1.);   /* a NaN ratio: the reference stops (:519-521), the product rejects */
+        } else r = 0.;                                /* :491-493, :522-524 */
+        if (diag) { diag[4 * m] = (double)lq_fwd; diag[4 * m + 1] = (double)lq_rev; diag[4 * m + 2] = norm2(d0, Nv); diag[4 * m + 3] = nd1; }
+        if (u_mh[m] <= r) {
+            memcpy(params + (size_t)m * Np, p_new, (size_t)Np * sizeof(double));
+            memcpy(vars + (size_t)m * Nv, v_new, (size_t)Nv * sizeof(double));
+            logL[m] = l; logPrior[m] = pr; logPost[m] = po;
+            moved[m] = 1;
+        } else moved[m] = 0;
+        Pmove[m] = r;
+        free(g); free(gp); free(d0); free(d1); free(mean); free(v_new); free(p_new); free(model); free(Mm);
+    }
+    /* adaptation after every chain has been tested: chain 0's mean feeds the steps h of the NEXT iteration only */
+    if (learn)
+        for (long m = 0; m < C; m++)
+            if (!chain_mask || chain_mask[m]) orc_update_proposal(mu + (size_t)m * Nv, covarmat + (size_t)m * Nv * Nv, sigma + m, vars + (size_t)m * Nv, Nv, Pmove[m], gamma,
+                                S->target_acceptance, S->epsilon1, S->A1);
+    *swapped = 0;
+    if (do_swap) {
+        double Pswap;
+        *swapped = orc_parallel_tempering(logL, logPrior, logPost, vars, params, moved, Pmove, S->Tcoefs, Nv, Np, ind_A, u_swap, literal_444, &Pswap);
+    }
+    free(h);
     return fatal ? -1 : 0;
 }

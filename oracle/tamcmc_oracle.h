@@ -192,6 +192,15 @@ int orc_sampler_iteration(const orc_sampler_star *S, long i, int learn, int do_s
                           const double *u_mh, double *params, double *vars, double *logL, double *logPrior, double *logPost, int *moved,
                           double *Pmove, double *mu, double *covarmat, double *sigma, int *swapped, double *prop_vars, double *prop_stats);
 
+/* ---- the Langevin step (use_drift = 1; the reference's D_MALA / multinormal_logpdf are stubs, MALA.cpp:321-337): sampler_oracle.c ---- */
+long double orc_mvn_logpdf(const double *v, const double *mean, const double *M, long n);
+int orc_fd_gradient_posterior(const orc_sampler_star *S, const double *params, double Tcoef, const double *h, double *grad, double *gradP);
+void orc_langevin_drift(const double *covarmat, double sigma, double epsi2, double delta, const double *grad, long Nvars, double *drift);
+int orc_langevin_iteration(const orc_sampler_star *S, long i, int learn, int do_swap, int ind_A, double u_swap, int literal_444, const double *z,
+                           const double *u_mh, double fd_step_rel, double delta, double *params, double *vars, double *logL, double *logPrior,
+                           double *logPost, int *moved, double *Pmove, double *mu, double *covarmat, double *sigma, int *swapped,
+                           double *prop_vars, double *prop_stats, double *diag, const int *chain_mask);
+
 #ifdef __cplusplus
 }
 #endif

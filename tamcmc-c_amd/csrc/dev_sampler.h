@@ -78,6 +78,9 @@ class DevSampler {
     int download_state(double *vars, double *params, double *logL, double *logPr, double *logPost, double *Pmove,
                        int *moved, long *counters);
     int download_proposal(int m, double *cov, double *mu, double *sigma);
+    // [0] Nvars [1] Nparams [2] adaptation workspace in LDS (1) / global scratch (0) [3] fused step available [4] chain groups
+    // [5] iterations run fused [6] iterations run by the lockstep kernels [7] chains
+    void info(long out[8]) const;
     int run(long it0, long n_iter, const char *learn, double *samples, double *stats);
     int run_mala(long it0, long n_iter, const char *learn, double *samples, double *stats);  // use_drift = 1 (dev_mala_impl.h)
 };

@@ -1195,6 +1195,8 @@ struct DevSampler::Impl {
     // follows and the L z of the one after; a call that continues right there starts without the two entry launches
     long armed_it = -1;
     int armed_q = 0;
+    long it_fused = 0, it_lockstep = 0;  // iterations run by each scheme since creation (tamcmc_sampler_get_info)
+    int mala_chol_lds = -1;
 
     hipEvent_t gev[8][2];  // fused step with two chain groups: event pairs around sampled launches of the second group (on its stream)
     int n_gev = 0;
@@ -1213,16 +1215,22 @@ struct DevSampler::Impl {
     // The caller's record buffer as the device sees it when it is pinned, mapped host memory (tamcmc_hip_host_alloc): the settle step then
     // writes the records straight into it (15 KB per iteration over PCIe, posted) and a call ends without its two device-to-host copies.
     // (asked on every call: an address says nothing about what the caller has freed and allocated since the last one)
-    double *device_view(const double *host) {
-        if (!host) return nullptr;
+    double *device_view(const double *host, size_t bytes) {
+        if (!host || !bytes) return nullptr;
         hipPointerAttribute_t at;
         double *d = nullptr;
-        void *dp = nullptr;
-        // (the device address of THIS address: hipHostGetDevicePointer; the attributes only tell that the memory is page-locked)
+        void *dp = nullptr, *dq = nullptr;
+        const char *last = (const char *)host + bytes - 1;
+        // (the device address of THIS address: hipHostGetDevicePointer; the attributes only tell that the memory is page-locked.)  The
+        // whole record block [host, host + bytes) must lie inside ONE mapping: the last byte has to be page-locked too and map to the
+        // first byte's device address + bytes - 1 -- a pinned buffer shorter than the call's records, or an interior pointer near the
+        // end of one, would otherwise make the settle step write outside the mapping (a GPU fault instead of a host-side error)
         if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dp, const_cast<double *>(host), 0) == hipSuccess && dp)
+            hipHostGetDevicePointer(&dp, const_cast<double *>(host), 0) == hipSuccess && dp &&
+            hipPointerGetAttributes(&at, last) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dq, const_cast<char *>(last), 0) == hipSuccess && dq == (char *)dp + bytes - 1)
             d = (double *)dp;
-        else (void)hipGetLastError();  // (pageable memory: not an error for us)
+        else (void)hipGetLastError();  // (pageable memory, or not one mapping over the whole block: the staged copy is used)
         return d;
     }
 
@@ -1241,6 +1249,8 @@ DevSampler::~DevSampler() {
     if (impl->ctx) {
         (void)hipSetDevice(impl->ctx->device);
         (void)hipStreamSynchronize(impl->ctx->stream);
+        // after a HIP error in the middle of a call the other chain groups' streams may still hold launches that use the buffers below
+        for (int g = 1; g < 4; g++) if (impl->gst[g]) (void)hipStreamSynchronize(impl->gst[g]);
     }
 #ifdef TAMCMC_PROBE
     if (impl->a.counters && getenv("TAMCMC_PROBE_ADAPT")) {
@@ -1403,6 +1413,14 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     return TAMCMC_OK;
 }
 
+void DevSampler::info(long out[8]) const {
+    const Impl &I = *impl;
+    out[0] = I.a.Nv; out[1] = I.a.desc.Np;
+    out[2] = I.use_drift ? I.mala_chol_lds : I.a.chol_in_lds;
+    out[3] = (I.fused_ok && !I.use_drift) ? 1 : 0;
+    out[4] = I.G; out[5] = I.it_fused; out[6] = I.it_lockstep; out[7] = I.a.C;
+}
+
 int DevSampler::upload_state(const double *vars, const double *params, const double *logL, const double *logPr,
                              const double *logPost, const double *init_logL) {
     Impl &I = *impl;
@@ -1556,7 +1574,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     // length (the reference's Nbuffer) or a short call after a shorter one never pays an allocation -- nor, with it, new kernel
     // arguments -- in its steady state (older, smaller buffers are released with the sampler)
     auto grown = [](size_t need, size_t have, size_t unit) { const size_t floor_ = 256 * unit; return std::max(std::max(need, floor_), have * 2); };
-    double *zc_smp = I.device_view(samples), *zc_st = I.device_view(stats);
+    double *zc_smp = I.device_view(samples, (size_t)n_iter * C * Nv * 8), *zc_st = I.device_view(stats, (size_t)n_iter * C * 3 * 8);
     if (samples && !zc_smp && I.smp_cap < (size_t)n_iter * C * Nv) {
         const size_t cap = grown((size_t)n_iter * C * Nv, I.smp_cap, C * Nv);
         DCHK(I.dalloc(&a.samples, cap));
@@ -1629,6 +1647,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     // ---- (B) one iteration per round over [ia, ib): k_iterate settles iteration it-1 and proposes iteration it
     auto lockstep = [&](long ia, long ib) -> int {
         I.armed_it = -1;
+        I.it_lockstep += ib - ia;
         // the extra streams start after everything already enqueued on the context stream
         if (G > 1) {
             DCHK(hipEventRecord(I.ev_fork, st));
@@ -1720,6 +1739,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         const int nlz2 = ((2 * a.C + 7) / 8) * 8;
         const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
         const long len = ib - ia;
+        I.it_fused += len;
         int q = P;
         StepCtl sc{};
         {  // device-memory image of the two argument blocks (re-uploaded only when a pointer or size changed since the last run)
@@ -1912,7 +1932,8 @@ int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *sampl
         FdBatch nb;
         int rc = nb.layout(c, I.model_id, I.prior_class, a.C, (int64_t)Np, I.h_plength.data(), a.Nv);
         if (rc) return rc;
-        if (nb.total_bytes != I.fd.total_bytes || nb.windowed != I.fd.windowed || nb.ntiles != I.fd.ntiles || !I.fd_block.p) {
+        const bool need_bg = c->precision == TAMCMC_PRECISION_FAST && !I.fd_bg.p;  // (a switch to FAST between two calls keeps every size)
+        if (nb.total_bytes != I.fd.total_bytes || nb.windowed != I.fd.windowed || nb.ntiles != I.fd.ntiles || !I.fd_block.p || need_bg) {
             I.fd = nb;
             rc = fd_ensure_poly(c);
             if (rc) return rc;
@@ -1952,6 +1973,8 @@ int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *sampl
     const size_t lds_test0 = (5 * Nv + 8) * sizeof(double) + 32, lds_adapt = (Nv * Nv + Nv) * sizeof(double);
     const bool chol_lds = lds_test0 + lds_adapt <= 156 * 1024;
     args.chol_in_lds = chol_lds ? 1 : 0;
+    I.mala_chol_lds = args.chol_in_lds;
+    I.it_lockstep += n_iter;
     if (!chol_lds && !I.adapt_scratch) DCHK(I.dalloc(&I.adapt_scratch, C * (Nv * Nv + Nv)));
     if (lds_test0 + lds_adapt > 64 * 1024 && chol_lds)
         DCHK(hipFuncSetAttribute((const void *)k_mala_test, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_test0 + lds_adapt)));

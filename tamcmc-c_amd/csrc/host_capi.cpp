@@ -153,6 +153,27 @@ void tamcmc_sampler_destroy(tamcmc_sampler *s) {
 
 int64_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->cur->get_Nvars() : -1; }
 
+int tamcmc_sampler_get_info(const tamcmc_sampler *s, int64_t *info, int32_t n) {
+    if (!s || !info || n < 1) return TAMCMC_ERR_BAD_ARG;
+    int64_t v[TAMCMC_SAMPLER_INFO_N] = {0};
+    v[TAMCMC_INFO_ENGINE] = s->dev ? 1 : 0;
+    v[TAMCMC_INFO_NVARS] = s->cur->get_Nvars();
+    v[TAMCMC_INFO_NPARAMS] = s->cur->get_Nparams();
+    v[TAMCMC_INFO_NCHAINS] = s->cfg.MALA.Nchains;
+    v[TAMCMC_INFO_ADAPT_IN_LDS] = -1;
+    if (s->dev) {
+        long d[8];
+        s->dev->info(d);
+        v[TAMCMC_INFO_ADAPT_IN_LDS] = d[2];
+        v[TAMCMC_INFO_FUSED_AVAILABLE] = d[3];
+        v[TAMCMC_INFO_CHAIN_GROUPS] = d[4];
+        v[TAMCMC_INFO_ITER_FUSED] = d[5];
+        v[TAMCMC_INFO_ITER_LOCKSTEP] = d[6];
+    }
+    for (int32_t i = 0; i < n && i < TAMCMC_SAMPLER_INFO_N; i++) info[i] = v[i];
+    return TAMCMC_OK;
+}
+
 int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, double *stats) {
     if (!s || n_iter < 0) return TAMCMC_ERR_BAD_ARG;
     const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();

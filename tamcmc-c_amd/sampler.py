@@ -24,6 +24,7 @@ EXTRA_ABI += [
     ("tamcmc_sampler_create", C.c_int, [C.POINTER(_vp), _vp, C.POINTER(SamplerConfig)]),
     ("tamcmc_sampler_destroy", None, [_vp]),
     ("tamcmc_sampler_nvars", C.c_int64, [_vp]),
+    ("tamcmc_sampler_get_info", C.c_int, [_vp, _i64p, C.c_int32]),
     ("tamcmc_sampler_run", C.c_int, [_vp, C.c_int64, _dp, _dp]),
     ("tamcmc_sampler_run_packed", C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int64, C.POINTER(_dp), C.POINTER(_dp)]),
     ("tamcmc_sampler_draws", C.c_int, [_vp, C.c_int64, _dp, _dp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -121,8 +122,9 @@ class Sampler:
         if out is not None:
             smp, stt = out
             record, stats = smp is not None, stt is not None
-            assert smp is None or (smp.flags.c_contiguous and smp.dtype == np.float64 and smp.shape == (n_iter, self.nchains, self.nvars))
-            assert stt is None or (stt.flags.c_contiguous and stt.dtype == np.float64 and stt.shape == (n_iter, self.nchains, 3))
+            for arr, shape, what in ((smp, (n_iter, self.nchains, self.nvars), "samples"), (stt, (n_iter, self.nchains, 3), "stats")):
+                if arr is not None and not (isinstance(arr, np.ndarray) and arr.flags.c_contiguous and arr.dtype == np.float64 and arr.shape == shape):
+                    raise ValueError(f"out: {what} must be a C-contiguous float64 array of shape {shape}")  # (the library writes that many bytes)
         else:
             smp = np.zeros((n_iter, self.nchains, self.nvars)) if record else None
             stt = np.zeros((n_iter, self.nchains, 3)) if stats else None
@@ -140,6 +142,15 @@ class Sampler:
                                          _p(out["Pmove"]), _p(out["sigma"]), _p(cnt, _i64p))
         out.update(iteration=int(cnt[0]), accepted0=int(cnt[1]), swap_attempts=int(cnt[2]), swaps=int(cnt[3]))
         return out
+
+    def info(self):
+        """tamcmc_sampler_get_info as a dict (engine, sizes, which side of the size limits, iterations per scheme)."""
+        v = np.zeros(9, dtype=np.int64)
+        rc = self._L.tamcmc_sampler_get_info(self._h, _p(v, _i64p), 9)
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_get_info")
+        keys = ("engine", "nvars", "nparams", "nchains", "adapt_in_lds", "fused_available", "chain_groups", "iter_fused", "iter_lockstep")
+        return dict(zip(keys, (int(x) for x in v)))
 
     def draws(self, iteration):
         """The random numbers iteration `iteration` consumes: (z [Nchains x Nvars], u_accept [Nchains], u_swap, ind_A)."""

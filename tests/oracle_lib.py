@@ -144,6 +144,16 @@ def load(fast=False):
     lib.orc_sampler_iteration.restype = C.c_int
     lib.orc_sampler_iteration.argtypes = [C.POINTER(SamplerStar), C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, c_dp, c_dp, c_dp,
                                           c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp]
+    # the Langevin step (sampler_oracle.c, second half)
+    lib.orc_mvn_logpdf.restype = ld
+    lib.orc_mvn_logpdf.argtypes = [c_dp, c_dp, c_dp, C.c_long]
+    lib.orc_fd_gradient_posterior.restype = C.c_int
+    lib.orc_fd_gradient_posterior.argtypes = [C.POINTER(SamplerStar), c_dp, C.c_double, c_dp, c_dp, c_dp]
+    lib.orc_langevin_drift.restype = None
+    lib.orc_langevin_drift.argtypes = [c_dp, C.c_double, C.c_double, C.c_double, c_dp, C.c_long, c_dp]
+    lib.orc_langevin_iteration.restype = C.c_int
+    lib.orc_langevin_iteration.argtypes = [C.POINTER(SamplerStar), C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, c_dp, C.c_double,
+                                           C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_ip]
     return lib
 
 
@@ -209,28 +219,65 @@ class Oracle:
         return rc, out
 
     # ---- one sampler iteration with explicit draws (sampler_oracle.c) ----
+    def _sampler_star(self, star, y, Tcoefs, init_logL, nparams, nvars, p, epsilon1, epsilon2, A1, target_acceptance, c0):
+        f = lambda a: np.ascontiguousarray(np.array(a, dtype=np.float64, copy=True))
+        T = f(Tcoefs)
+        keep = dict(pl=np.ascontiguousarray(star.plength, dtype=np.int32), idx=np.ascontiguousarray(star.index_to_relax, dtype=np.int32),
+                    sw=np.ascontiguousarray(star.priors_switch, dtype=np.int32), pr=f(star.priors), ex=f(np.resize(np.append(star.extra_priors, np.zeros(10)), 10)),
+                    x=f(star.x), y=f(y), T=T, il=f(init_logL if init_logL is not None else np.zeros(T.size)))
+        S = self.lib.SamplerStar(int(star.model_id), int(star.prior_class), int(nparams), int(nvars), keep["x"].size, T.size, _ip(keep["pl"]),
+                                 _ip(keep["idx"]), _ip(keep["sw"]), _dp(keep["pr"]), _dp(keep["ex"]), _dp(keep["x"]), _dp(keep["y"]), _dp(keep["T"]),
+                                 _dp(keep["il"]), float(p), epsilon1, epsilon2, A1, target_acceptance, c0)
+        return S, keep
+
     def sampler_iteration(self, star, y, Tcoefs, init_logL, state, law, i, z, u_mh, learn=False, do_swap=False, ind_A=0, u_swap=1.0,
-                          literal_444=False, p=1.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, target_acceptance=0.234, c0=10.0):
+                          literal_444=False, p=1.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, target_acceptance=0.234, c0=10.0,
+                          use_drift=False, fd_step_rel=1e-7, delta=0.0, chain_mask=None):
         """One pass of MALA::execute's loop body.  state = dict(params, vars, logL, logPrior, logPost) [copied], law = (mu, cov, sigma)
-        [copied].  Returns (new state incl. moved / Pmove / swapped / prop_vars / prop_stats, new law, rc)."""
+        [copied].  Returns (new state incl. moved / Pmove / swapped / prop_vars / prop_stats, new law, rc).
+        use_drift: the Langevin step (orc_langevin_iteration); the state then also carries diag [Nchains x 4] = log q(x'|x), log q(x|x'),
+        |drift(x)|, |drift(x')|; chain_mask [Nchains]: advance the flagged chains only."""
         f = lambda a: np.ascontiguousarray(np.array(a, dtype=np.float64, copy=True))
         st = {k: f(state[k]) for k in ("params", "vars", "logL", "logPrior", "logPost")}
         mu, cov, sigma = f(law[0]), f(law[1]), f(law[2])
         C_, Nv = st["vars"].shape
-        keep = dict(pl=np.ascontiguousarray(star.plength, dtype=np.int32), idx=np.ascontiguousarray(star.index_to_relax, dtype=np.int32),
-                    sw=np.ascontiguousarray(star.priors_switch, dtype=np.int32), pr=f(star.priors), ex=f(np.resize(np.append(star.extra_priors, np.zeros(10)), 10)),
-                    x=f(star.x), y=f(y), T=f(Tcoefs), il=f(init_logL))
-        S = self.lib.SamplerStar(int(star.model_id), int(star.prior_class), st["params"].shape[1], Nv, keep["x"].size, C_, _ip(keep["pl"]),
-                                 _ip(keep["idx"]), _ip(keep["sw"]), _dp(keep["pr"]), _dp(keep["ex"]), _dp(keep["x"]), _dp(keep["y"]), _dp(keep["T"]),
-                                 _dp(keep["il"]), float(p), epsilon1, epsilon2, A1, target_acceptance, c0)
+        S, keep = self._sampler_star(star, y, Tcoefs, init_logL, st["params"].shape[1], Nv, p, epsilon1, epsilon2, A1, target_acceptance, c0)
         z, u = f(z), f(u_mh)
         moved, Pmove, swapped = np.zeros(C_, dtype=np.int32), np.zeros(C_), np.zeros(1, dtype=np.int32)
         pv, ps = np.zeros((C_, Nv)), np.zeros((C_, 3))
-        rc = self.lib.orc_sampler_iteration(C.byref(S), int(i), int(learn), int(do_swap), int(ind_A), float(u_swap), int(literal_444), _dp(z), _dp(u),
-                                            _dp(st["params"]), _dp(st["vars"]), _dp(st["logL"]), _dp(st["logPrior"]), _dp(st["logPost"]), _ip(moved),
-                                            _dp(Pmove), _dp(mu), _dp(cov), _dp(sigma), _ip(swapped), _dp(pv), _dp(ps))
+        if use_drift:
+            diag = np.zeros((C_, 4))
+            rc = self.lib.orc_langevin_iteration(C.byref(S), int(i), int(learn), int(do_swap), int(ind_A), float(u_swap), int(literal_444), _dp(z),
+                                                 _dp(u), float(fd_step_rel), float(delta), _dp(st["params"]), _dp(st["vars"]), _dp(st["logL"]),
+                                                 _dp(st["logPrior"]), _dp(st["logPost"]), _ip(moved), _dp(Pmove), _dp(mu), _dp(cov), _dp(sigma),
+                                                 _ip(swapped), _dp(pv), _dp(ps), _dp(diag),
+                                                 _ip(np.ascontiguousarray(chain_mask, dtype=np.int32)) if chain_mask is not None else None)
+            st["diag"] = diag
+        else:
+            rc = self.lib.orc_sampler_iteration(C.byref(S), int(i), int(learn), int(do_swap), int(ind_A), float(u_swap), int(literal_444), _dp(z), _dp(u),
+                                                _dp(st["params"]), _dp(st["vars"]), _dp(st["logL"]), _dp(st["logPrior"]), _dp(st["logPost"]), _ip(moved),
+                                                _dp(Pmove), _dp(mu), _dp(cov), _dp(sigma), _ip(swapped), _dp(pv), _dp(ps))
         st.update(moved=moved, Pmove=Pmove, swapped=int(swapped[0]), prop_vars=pv, prop_stats=ps)
         return st, (mu, cov, sigma), rc
+
+    def mvn_logpdf(self, v, mean, M):
+        v, mean, M = (np.ascontiguousarray(a, dtype=np.float64) for a in (v, mean, M))
+        return float(self.lib.orc_mvn_logpdf(_dp(v), _dp(mean), _dp(M), v.size))
+
+    def langevin_drift(self, cov, sigma, epsi2, delta, grad):
+        cov, grad = np.ascontiguousarray(cov, dtype=np.float64), np.ascontiguousarray(grad, dtype=np.float64)
+        out = np.zeros(grad.size)
+        self.lib.orc_langevin_drift(_dp(cov), float(sigma), float(epsi2), float(delta), _dp(grad), grad.size, _dp(out))
+        return out
+
+    def fd_gradient_posterior(self, star, y, params, Tcoef, h, p=1.0):
+        """(status of the base point, gradient of logL/T + logPrior, the prior's share) by forward differences with the steps h."""
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        S, keep = self._sampler_star(star, y, [Tcoef], None, params.size, h.size, p, 1e-12, 1e-12, 1e14, 0.234, 10.0)
+        g, gp = np.zeros(h.size), np.zeros(h.size)
+        st = self.lib.orc_fd_gradient_posterior(C.byref(S), _dp(params), float(Tcoef), _dp(h), _dp(g), _dp(gp))
+        return st, g, gp
 
     def amplitude_ratio(self, l, inc_deg):
         v = np.zeros(2 * l + 1)

@@ -117,6 +117,128 @@ def test_one_iteration_equals_the_oracle_at_the_headline_shape(pkg, oracle, c3, 
     s.close()
 
 
+def _one_langevin_iteration_against_oracle(oracle, star, y, T, s, init_logL, learn, c0, fd_step_rel, delta, report, check=None):
+    """One settled Langevin iteration of the product against oracle/sampler_oracle.c::orc_langevin_iteration fed with the same draws.  The
+    oracle recomputes every gradient from the position (term-by-term long double differences) and evaluates both proposal densities as
+    full multivariate-normal densities by pivoted elimination -- the product carries gradients along, re-tempers them on swaps and uses
+    two triangular solves with its Cholesky factor.  Stated tolerances: positions 1e-9 relative (the product's forward differences
+    divide its 1e-12-per-bin FAST arithmetic by steps of 1e-7 |theta|: gradients, hence drifts, to ~1e-5), log-posteriors 1e-9 relative,
+    move probabilities 2e-3 relative (absolute error of the exponent ~1e-4: ~1e5-sized log-posteriors at 2e-11, two quadratic forms).
+    check: the chains the oracle advances and the comparison covers (None = all; the swap pair is always among them)."""
+    nch = len(T)
+    st = s.state()
+    params = np.tile(star.params, (nch, 1))
+    params[:, star.index_to_relax] = st["vars"]
+    before = dict(params=params, vars=st["vars"], logL=st["logL"], logPrior=st["logPrior"], logPost=st["logPost"])
+    law = s.proposal_law()
+    it = st["iteration"]
+    z, u, u_swap, ind_A = s.draws(it)
+    mask = np.ones(nch, dtype=np.int32)
+    if check is not None:
+        mask[:] = 0
+        mask[list(check)] = 1
+        if it != 0:
+            mask[[ind_A, ind_A + 1]] = 1
+    c = np.flatnonzero(mask)
+    exp, law2, rc = oracle.sampler_iteration(star, y, T, init_logL, before, law, i=it, z=z, u_mh=u, learn=learn, do_swap=it != 0, ind_A=ind_A,
+                                             u_swap=u_swap, c0=c0, use_drift=True, fd_step_rel=fd_step_rel, delta=delta, chain_mask=mask)
+    assert rc == 0
+    smp, stt = s.run(1, stats=True)
+    aft = s.state()
+    assert aft["iteration"] == it + 1
+    # the comparators were drawn by the product's generator, not chosen: a chain whose comparator lies within the tolerance of its move
+    # probability may fall either way and is left out of this iteration's comparison (with its swap partner); every iteration starts from
+    # the product's own state, so nothing carries over
+    r_test, u_test = exp["Pmove"].copy(), u
+    if exp["swapped"]:
+        r_test[[ind_A, ind_A + 1]] = r_test[[ind_A + 1, ind_A]]             # Pmove travels with the rows (MALA.cpp:437, :447)
+    knife = np.abs(r_test - u_test) < 5e-3 * r_test
+    if it != 0 and (knife[ind_A] or knife[ind_A + 1]):
+        knife[[ind_A, ind_A + 1]] = True
+    c = np.array([m for m in c if not knife[m]], dtype=int)
+    assert c.size >= max(1, mask.sum() - 3)
+    dv = np.max(np.abs(aft["vars"][c] - exp["vars"][c]) / (np.abs(exp["vars"][c]) + 1e-2))
+    dP = np.max(np.abs(aft["Pmove"][c] - exp["Pmove"][c]) / np.maximum(exp["Pmove"][c], 1e-300))
+    dL = np.max(np.abs(aft["logPost"][c] - exp["logPost"][c]) / np.abs(exp["logPost"][c]))
+    report.append((it, learn, int(exp["moved"][c].sum()), exp["swapped"], dv, dL, dP))
+    assert dv < 1e-9, (it, dv)
+    assert np.array_equal(smp[0], aft["vars"])
+    assert np.allclose(aft["logL"][c], exp["logL"][c], rtol=1e-9, atol=0) and np.allclose(aft["logPost"][c], exp["logPost"][c], rtol=1e-9, atol=0)
+    assert np.allclose(aft["logPrior"][c], exp["logPrior"][c], rtol=1e-9, atol=1e-9)
+    assert np.allclose(stt[0][c, 0], exp["logL"][c], rtol=1e-9) and np.allclose(stt[0][c, 2], exp["logPost"][c], rtol=1e-9)
+    assert np.allclose(aft["Pmove"][c], exp["Pmove"][c], rtol=2e-3, atol=1e-300), (it, dP)
+    if learn:
+        mu, cov, sig = s.proposal_law()
+        assert np.allclose(mu[c], law2[0][c], rtol=1e-10, atol=1e-12)
+        assert np.allclose(sig[c], law2[2][c], rtol=0, atol=2e-3 * c0 / (1 + it) + 1e-12)          # sigma moves by gamma (Pmove - target)
+        assert np.allclose(cov[c], law2[1][c], rtol=1e-8, atol=1e-8 * np.abs(law2[1][c]).max())
+    return exp, ind_A
+
+
+def _langevin_walk(pkg, oracle, star, y, ctx, nch, lam, engine, seed, fd_step_rel, delta, adapt_to, n_settle, want_swaps, check=None):
+    """The checked walk: from the start point (no adaptation, iteration 0 without a swap step), two adapting iterations, the rest of the
+    adaptation window unchecked, then settled iterations whose swap pair / comparator are chosen so that accepted and refused swaps (for
+    the two-group layouts: inside a group and across the groups) are among them -- each FOLLOWED by a second checked iteration, whose
+    drifts come from the gradients the product carried through the swap (likelihood share re-tempered) where the oracle recomputes them
+    at the new temperatures."""
+    c0 = 2.0
+    T = lam ** np.arange(nch)
+    s = pkg.Sampler(ctx, star, nchains=nch, lambda_temp=lam, engine=engine, use_drift=1, seed=seed, Nt_learn=(4, adapt_to), periods_learn=(1,),
+                    dN_mixing=1, c0=c0, fd_step_rel=fd_step_rel, delta=delta)
+    init_logL = s.state()["logL"].copy()
+    rep, moved, refused, swapped, kept, visible = [], 0, 0, 0, 0, 0
+    one = lambda learn: _one_langevin_iteration_against_oracle(oracle, star, y, T, s, init_logL, learn, c0, fd_step_rel, delta, rep, check)
+    for _ in range(2):
+        one(False)
+    s.run(2, record=False)
+    for _ in range(2):
+        one(True)
+    s.run(adapt_to - 6, record=False)
+    assert s.state()["iteration"] == adapt_to
+    s.run(n_settle, record=False)
+    vars_now = s.state()["vars"]
+    for want_A, (u_lo, u_hi) in want_swaps:
+        k = _find_iteration(s, 5000, want_A, u_lo, u_hi)
+        s.set_state(vars_now, iteration=k)
+        for j in range(2):
+            exp, ia = one(False)
+            if j == 0:
+                assert ia == want_A
+                swapped += int(exp["swapped"])
+                kept += int(not exp["swapped"])
+            moved += int(exp["moved"].sum())
+            refused += int((exp["moved"] == 0).sum())
+            visible += int(np.any((exp["Pmove"] > 1e-6) & (exp["Pmove"] < 1)))     # the correction term is visible in a move probability
+        vars_now = s.state()["vars"]
+    s.close()
+    print("\nlangevin walk", engine, "nch", nch, "delta", delta, "\n     it learn moved swapped dvars dlogPost dPmove")
+    for r in rep:
+        print("  %6d %d %3d %d  %.2e %.2e %.2e" % r)
+    assert moved >= 1 and refused >= 1 and swapped >= 1 and kept >= 1 and visible >= 2, (moved, refused, swapped, kept, visible)
+
+
+@pytest.mark.parametrize("engine", ["host", "device"])
+@pytest.mark.parametrize("delta", [0.0, 30.0])
+def test_langevin_iteration_equals_the_oracle_on_a_local_slice(pkg, oracle, synth, engine, delta):
+    """C2 family: local slice, 1e4 bins, 21 free variables, 10 chains; with and without truncation of the drift."""
+    star = synth.make_c2_star(nx=10000)
+    _, m0 = oracle.call_model(star.model_id, star.params, star.plength, star.x)
+    y = star.set_spectrum_from_model(m0, seed=11)
+    ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
+    ctx.set_spectrum(star.x, y)
+    _langevin_walk(pkg, oracle, star, y, ctx, 10, 1.7, engine, 5, 1e-7, delta, adapt_to=150, n_settle=20,
+                   want_swaps=((2, (0.0, 0.05)), (4, (0.0, 0.05)), (4, (0.97, 1.0)), (7, (0.97, 1.0))))
+    ctx.close()
+
+
+@pytest.mark.parametrize("engine", ["host", "device"])
+def test_langevin_iteration_equals_the_oracle_at_the_headline_shape(pkg, oracle, c3, engine):
+    """The north star's named step at C3 size: 1e5 bins x 111 parameters (93 free) x 20 tempered chains."""
+    star, ctx = c3
+    _langevin_walk(pkg, oracle, star, star.y, ctx, NCH, LAM, engine, 31, 1e-7, 0.0, adapt_to=120, n_settle=10,
+                   want_swaps=((3, (0.0, 0.01)), (NCH // 2 - 1, (0.0, 0.01)), (NCH // 2 - 1, (0.97, 1.0))), check=(0, 10, NCH - 1))
+
+
 def test_langevin_at_the_headline_shape(pkg, oracle, c3):
     """North star's named path at C3 size on the DEVICE engine: the forward-difference gradient that drives the Langevin proposal equals the
     oracle's finite differences of the reference log-likelihood (same steps), and the sampler it drives accepts at a healthy rate after
