@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--rgb-steps", type=int, default=150,
                     help="extra leg at N=1: BASELINE configs[4] family (red giant, model id 25, 2e5 bins, 40 chains; host-driven engine with the "
                          "mixed-mode solver on the device), this many timed iterations (0 = skip); reported under 'c5_rgb'")
+    ap.add_argument("--learn-steps", type=int, default=1500,
+                    help="extra leg at N=1: the same star in the LEARNING phase -- the proposal law adapted after every test (MALA.cpp:656-667, "
+                         "config_default.cfg:17-18), this many timed iterations (0 = skip); reported under 'learning', never as 'value'")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed headline run (no packed / red-giant / MALA / launch-shape / CPU legs): the command profiled under "
                          "rocprofv3 for profiles/, so that the per-kernel averages are those of the headline launches")
@@ -72,7 +75,7 @@ def parse():
     a.steps = max(a.steps, 1)
     a.warmup = max(a.warmup, 0)
     if a.headline_only:
-        a.mala_steps, a.packed_stars, a.rgb_steps, a.no_cpu_baseline = 0, 0, 0, True
+        a.mala_steps, a.packed_stars, a.rgb_steps, a.learn_steps, a.no_cpu_baseline = 0, 0, 0, 0, True
     return a
 
 
@@ -241,6 +244,29 @@ def main():
                                                  "(not 16 B x Nx per evaluation: a perturbed mode parameter changes the model inside its window only)"}}
         ms.close()
         mark("extra leg: mala_fd")
+
+    if a.learn_steps > 0 and a.sampler == "mh" and world == 1:
+        # the Learning phase of the reference's processing chain (config_presets.cfg:26-31; by default 700 000 of a run's samples): every
+        # iteration ends with the Robbins-Monro update of mu, Sigma, sigma and a new Cholesky factor (MALA.cpp:296-319, :339-350)
+        ls = pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, seed=11 + rank, engine=a.engine, Nt_learn=(100, 10**9), periods_learn=(1,),
+                         dN_mixing=a.dn_mixing, c0=2.0)
+        ls.run(400, record=False)
+        lb = pkg.pinned_empty((a.learn_steps, a.chains, ls.nvars)), pkg.pinned_empty((a.learn_steps, a.chains, 3))
+        ls.run(min(64, a.learn_steps), out=(lb[0][:min(64, a.learn_steps)], lb[1][:min(64, a.learn_steps)]))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ls.run(a.learn_steps, out=lb)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        lacc = np.mean(np.any(lb[0][1:] != lb[0][:-1], axis=2), axis=0)
+        extra["learning"] = {"iterations_per_s": a.learn_steps / e1, "us_per_iteration": 1e6 * e1 / a.learn_steps, "steps": a.learn_steps,
+                             "what": "C3 star, adaptation of the proposal law after every MH test (Robbins-Monro update + Cholesky factor of the "
+                                     f"{ls.nvars} x {ls.nvars} covariance per chain per iteration), samples and statistics recorded",
+                             "accept_rate_chain0": float(lacc[0]), "sigma_chain0": float(ls.state()["sigma"][0]),
+                             "alg_GBps": a.learn_steps / e1 * a.chains * 16.0 * a.nx / 1e9,
+                             "frac_of_hbm_peak": a.learn_steps / e1 * a.chains * 16.0 * a.nx / 1e9 / HBM_PEAK_GBS}
+        ls.close()
+        mark("extra leg: learning phase")
 
     if a.packed_stars > 1 and a.sampler == "mh" and a.engine == "device" and world == 1:
         # Several independent stars on ONE GPU (one context + one device-resident sampler + one host thread per star,

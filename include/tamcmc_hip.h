@@ -132,7 +132,15 @@ int tamcmc_hip_loglike_params_batch(tamcmc_hip_ctx *ctx, int model_id, int B, co
                                     const int32_t *plength, const double *Tcoefs, double p, double *logL,
                                     double *model, int32_t *status);
 
-/* Red-giant models (ids 25, 27): the l=1 mixed modes of ONE parameter vector as the device pre-step computes them for the table
+/* Red-giant tolerance (ids 25, 27; every arithmetic mode).  The reference evaluates the mixed-mode relation on its grids in double
+ * (Eigen arrays, solver_mm.cpp:158-169, called at :356-358 and :382-383) and the intersection test in long double (:179-186, :389-404); the device pre-step uses double
+ * throughout, the oracle long double throughout.  Stated: mixed-mode frequencies within 1e-10 muHz and zeta within 1e-9 of the oracle's,
+ * model rows ||dM||_2 / ||M||_2 <= 1e-10, |dlogL| / |logL| <= 1e-11 (STRICT) / the FAST tolerance above (FAST).  Measured on MI355X
+ * (tools/rgb_parity_probe.py, round 3): frequencies <= 3e-13 muHz (1.5e-11 at 2e5 bins with ~170 mixed modes), zeta <= 4e-13 (1.2e-10),
+ * rows <= 2e-12 (1.1e-11), logL <= 1e-14.  A mixed mode is as narrow as 0.01 muHz, so a frequency error d nu moves single bins of its
+ * profile by ~d nu / Gamma: the per-bin maximum is larger than the row norm (5e-12 typical, 5.5e-10 at the C5 size).
+ *
+ * Red-giant models (ids 25, 27): the l=1 mixed modes of ONE parameter vector as the device pre-step computes them for the table
  * (csrc/rgb_prestep.hip) -- what external/ARMM/do_solve.cpp:114-121 prints with the reference's solver:
  *   nu_m  = solve_mm_asymptotic_O2p / _O2from_l0 (solver_mm.cpp:470-760, chosen by the vector's model_type) + the spline bias,
  *   zeta  = ksi_fct2(nu_m, ..., "precise") (bump_DP.cpp:125-188),  h1_h0 = h_l_rgb(zeta, Hfactor) (bump_DP.cpp:235-254).

@@ -117,6 +117,11 @@ int tamcmc_sampler_draws(const tamcmc_sampler *s, int64_t iteration, double *z, 
  *   of chain 0, swap attempts, swaps accepted */
 int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL, double *logPrior, double *logPost,
                              double *Pmove, double *sigma, int64_t *counters);
+/* moves [Nchains]: for every chain the number of iterations since creation whose record carries moved = 1 -- the flag the reference
+ * stores per iteration and chain (MALA.cpp:543-545; a swap exchanges the pair's flags, :436, :446) and its acceptance diagnostic counts
+ * per buffer (Outputs::reject_rate / count_accepted_vals, outputs.cpp:1824-1858).  Differences between two calls / the iterations in
+ * between = the acceptance rates of that buffer (tamcmc_outputs_write_acceptance). */
+int tamcmc_sampler_get_move_counts(const tamcmc_sampler *s, int64_t *moves);
 /* proposal law of chain m: mu [Nvars], covarmat [Nvars x Nvars] (restore file content, outputs.cpp:863-1025) */
 int tamcmc_sampler_get_proposal(const tamcmc_sampler *s, int32_t m, double *mu, double *covarmat);
 int tamcmc_sampler_set_proposal(tamcmc_sampler *s, int32_t m, const double *mu, const double *covarmat, double sigma);
@@ -149,6 +154,13 @@ int tamcmc_outputs_write_params(const char *root, const double *samples, int64_t
 /* <root>stat_criteria.hdr/.bin: per sample logLikelihood[0:Nchains], logPrior[0:Nchains], logPosterior[0:Nchains];
  * stats = [n x Nchains x 3] as tamcmc_sampler_run returns them; append as above (outputs.cpp:1502). */
 int tamcmc_outputs_write_stat_criteria(const char *root, const double *stats, int64_t n, int32_t Nchains, int32_t append);
+/* <file>: the acceptance diagnostic the reference appends one line to per buffer (Outputs::write_txt_acceptance, outputs.cpp:747-790):
+ * x = (Ncopy + 0.5) Nbuffer + Nsamples_init (the buffer's average sample index, outputs.cpp:1838) followed by acceptance_rate[0:Nchains-1]
+ * streamed as an Eigen row (6 significant digits, columns padded to the widest entry).  first != 0 starts the file with its header. */
+int tamcmc_outputs_write_acceptance(const char *file, double xaxis, const double *rates, int32_t Nchains, int32_t first);
+/* reads it back: *Nchains from the header, then up to max_rows lines into xaxis [max_rows] and rates [max_rows x Nchains] (either may be
+ * NULL to query *n_rows) */
+int tamcmc_outputs_read_acceptance(const char *file, int32_t *Nchains, int64_t max_rows, int64_t *n_rows, double *xaxis, double *rates);
 /* reads back one chain (what tools/bin2txt_params.cpp does): the header's Nsamples_done rows; samples may be NULL to query the count */
 int tamcmc_outputs_read_params(const char *root, int32_t chain, double *samples, int64_t max_samples, int64_t *n_read,
                                int32_t *Nchains, int32_t *Nvars);

@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(TB) k_mala_settle(const DevSamplerArgs a, cons
             a.moved[m] = src_o.acc;
             a.Pmove[m] = src_o.r;
             if (m == 0 && src_o.acc) a.counters[1] += 1;
+            a.counters[8 + m] += src_o.acc;
             if (m == 0) a.counters[0] = it;
             if (a.stats && rec >= 0) {
                 double *r = a.stats + ((size_t)rec * C + m) * 3;

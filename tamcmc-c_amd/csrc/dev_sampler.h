@@ -31,7 +31,7 @@ struct DevSamplerArgs {
     double *vars_prop, *params_prop, *logPr_prop;
     int *status_prop, *moved;
     double *Pmove;
-    long *counters;       // [0] iteration, [1] accepted moves of chain 0, [2] swap attempts, [3] swaps accepted
+    long *counters;       // [0] iteration, [1] accepted moves of chain 0, [2] swap attempts, [3] swaps accepted, [8 + m] recorded moves of chain m
     // proposal law
     double *LT, *cov, *mu, *sigma;   // LT = transposed Cholesky factor of (cov+eps2)*sigma
     double *lz;           // [2][C][Nv] L z of the NEXT iteration, computed ahead by spare workgroups while L is frozen
@@ -76,7 +76,7 @@ class DevSampler {
                      const double *logPost, const double *init_logL);
     int upload_proposal(int m, const double *L_rowmajor, const double *cov, const double *mu, double sigma);
     int download_state(double *vars, double *params, double *logL, double *logPr, double *logPost, double *Pmove,
-                       int *moved, long *counters);
+                       int *moved, long *counters, long *moves_per_chain = nullptr);
     int download_proposal(int m, double *cov, double *mu, double *sigma);
     // [0] Nvars [1] Nparams [2] adaptation workspace in LDS (1) / global scratch (0) [3] fused step available [4] chain groups
     // [5] iterations run fused [6] iterations run by the lockstep kernels [7] chains

@@ -26,6 +26,8 @@
 // inter-workgroup synchronisation inside (B) and a launch never overwrites what it still reads in (A).  Both schemes keep the
 // chains' state in the same arrays; a stretch hands over to the next with the parity only.
 #include <hip/hip_runtime.h>
+
+#include <chrono>
 #include <hip/hip_ext.h>
 
 #include <cmath>
@@ -728,6 +730,7 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
             a.moved[m] = (src == m) ? s_own.acc : s_partner.acc;
             a.Pmove[m] = (src == m) ? s_own.r : s_partner.r;
             if (m == 0 && a.moved[0]) a.counters[1] += 1;
+            a.counters[8 + m] += a.moved[m];  // per-chain count of recorded moves (the acceptance diagnostic, outputs.cpp:1824-1858)
             if (m == 0) a.counters[0] = it;
             if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
                 double *r = a.stats + ((size_t)rec * C + m) * 3;
@@ -811,6 +814,7 @@ __device__ __forceinline__ void fused_scalars(const AT &a, const FT &f, int m, i
     a.moved[m] = src_acc;     // a swap exchanges the pair's moved / Pmove entries too (MALA.cpp:425-446)
     a.Pmove[m] = src_r;
     if (m == 0 && src_acc) a.counters[1] += 1;
+    a.counters[8 + m] += src_acc;
     if (m == 0) a.counters[0] = it + 1;
     if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
         double *r = a.stats + ((size_t)rec * C + m) * 3;
@@ -1217,21 +1221,32 @@ struct DevSampler::Impl {
     // (asked on every call: an address says nothing about what the caller has freed and allocated since the last one)
     double *device_view(const double *host, size_t bytes) {
         if (!host || !bytes) return nullptr;
-        hipPointerAttribute_t at;
         double *d = nullptr;
         void *dp = nullptr, *dq = nullptr;
         const char *last = (const char *)host + bytes - 1;
-        // (the device address of THIS address: hipHostGetDevicePointer; the attributes only tell that the memory is page-locked.)  The
-        // whole record block [host, host + bytes) must lie inside ONE mapping: the last byte has to be page-locked too and map to the
+        // hipHostGetDevicePointer fails for pageable memory and returns the device address of THIS address for page-locked, mapped memory.
+        // The whole record block [host, host + bytes) must lie inside ONE mapping: the last byte has to be page-locked too and map to the
         // first byte's device address + bytes - 1 -- a pinned buffer shorter than the call's records, or an interior pointer near the
         // end of one, would otherwise make the settle step write outside the mapping (a GPU fault instead of a host-side error)
-        if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dp, const_cast<double *>(host), 0) == hipSuccess && dp &&
-            hipPointerGetAttributes(&at, last) == hipSuccess && at.type == hipMemoryTypeHost &&
+        if (hipHostGetDevicePointer(&dp, const_cast<double *>(host), 0) == hipSuccess && dp &&
             hipHostGetDevicePointer(&dq, const_cast<char *>(last), 0) == hipSuccess && dq == (char *)dp + bytes - 1)
             d = (double *)dp;
         else (void)hipGetLastError();  // (pageable memory, or not one mapping over the whole block: the staged copy is used)
         return d;
+    }
+
+    // End of a call: the host waits for a stream by polling it for up to a millisecond before it blocks.  A blocking wait parks the
+    // thread on an interrupt and wakes tens of microseconds after the last kernel has finished -- a tenth of a 20-iteration call (the
+    // reference writes its ring buffer every Nbuffer iterations; a caller with short buffers makes short calls).
+    static hipError_t wait_stream(hipStream_t st) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0;; spin++) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipErrorNotReady) return e;
+            if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) break;
+        }
+        (void)hipGetLastError();  // (hipErrorNotReady is sticky in the last-error slot)
+        return hipStreamSynchronize(st);
     }
 
     template <typename T>
@@ -1345,7 +1360,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.vars_prop, 2 * CD * Nv)); DCHK(I.dalloc(&a.params_prop, 2 * CD * Np));
     DCHK(I.dalloc(&a.logL_cur, 2 * C)); DCHK(I.dalloc(&a.logPr_cur, 2 * C)); DCHK(I.dalloc(&a.logPost_cur, 2 * C));
     DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * CD)); DCHK(I.dalloc(&a.status_prop, 2 * CD));
-    DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8));
+    DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8 + C));
     a.grad_cur = nullptr; a.gradP_cur = nullptr;
     if (I.use_drift) {
         DCHK(I.dalloc(&a.grad_cur, 2 * C * Nv)); DCHK(I.dalloc(&a.gradP_cur, 2 * C * Nv));
@@ -1355,7 +1370,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.lz, 2 * C * Nv)); DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, CD * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * CD)); DCHK(I.dalloc(&a.nh, CD)); DCHK(I.dalloc(&a.nn, CD));
     DCHK(I.dalloc(&a.noise, CD * (size_t)a.desc.stride));
-    DCHK(hipMemsetAsync(a.counters, 0, 8 * sizeof(long), st));
+    DCHK(hipMemsetAsync(a.counters, 0, (8 + C) * sizeof(long), st));
     DCHK(hipMemsetAsync(a.moved, 0, C * sizeof(int), st));
     DCHK(hipMemsetAsync(a.Pmove, 0, C * sizeof(double), st));
     a.samples = nullptr; a.stats = nullptr;
@@ -1474,10 +1489,10 @@ int DevSampler::upload_proposal(int m, const double *L_rowmajor, const double *c
 }
 
 // gathers the chains' current state into one contiguous block: [vars C Nv | params C Np | logL C | logPr C | logPost C | Pmove C |
-// moved C (as double) | counters 4 (as double: exact below 2^53)]
+// moved C (as double) | counters 4 (as double: exact below 2^53) | per-chain move counts C]
 __global__ void __launch_bounds__(256) k_pack_state(const DevSamplerArgs a, const int P, double *out) {
     const size_t C = (size_t)a.C, Np = (size_t)a.desc.Np, Nv = (size_t)a.Nv;
-    const size_t n_v = C * Nv, n_p = C * Np, total = n_v + n_p + 5 * C + 4;
+    const size_t n_v = C * Nv, n_p = C * Np, total = n_v + n_p + 6 * C + 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         double v;
         if (i < n_v) v = a.vars_cur[(size_t)P * n_v + i];
@@ -1489,7 +1504,8 @@ __global__ void __launch_bounds__(256) k_pack_state(const DevSamplerArgs a, cons
             else if (k == 2) v = a.logPost_cur[(size_t)P * C + m];
             else if (k == 3) v = a.Pmove[m];
             else if (k == 4) v = (double)a.moved[m];
-            else v = (double)a.counters[r - 5 * C];
+            else if (r < 5 * C + 4) v = (double)a.counters[r - 5 * C];
+            else v = (double)a.counters[8 + (r - 5 * C - 4)];
         }
         out[i] = v;
     }
@@ -1497,14 +1513,14 @@ __global__ void __launch_bounds__(256) k_pack_state(const DevSamplerArgs a, cons
 
 // One small kernel + ONE copy into pinned memory (eight copies into pageable memory cost ~150 us per tamcmc_sampler_run call).
 int DevSampler::download_state(double *vars, double *params, double *logL, double *logPr, double *logPost, double *Pmove,
-                               int *moved, long *counters) {
+                               int *moved, long *counters, long *moves_per_chain) {
     Impl &I = *impl;
     tamcmc_hip_ctx *c = I.ctx;
     DevSamplerArgs &a = I.a;
     const size_t C = (size_t)a.C, Np = (size_t)a.desc.Np, Nv = (size_t)a.Nv;
     hipStream_t st = c->stream;
     DCHK(hipSetDevice(c->device));
-    const size_t n_v = C * Nv, n_p = C * Np, total = n_v + n_p + 5 * C + 4;
+    const size_t n_v = C * Nv, n_p = C * Np, total = n_v + n_p + 6 * C + 4;
     if (!I.d_pack) {
         DCHK(I.dalloc(&I.d_pack, total));
         DCHK(hipHostMalloc((void **)&I.h_pack, total * sizeof(double), hipHostMallocDefault));
@@ -1522,6 +1538,7 @@ int DevSampler::download_state(double *vars, double *params, double *logL, doubl
     if (Pmove) std::memcpy(Pmove, sc + 3 * C, C * 8);
     if (moved) for (size_t m = 0; m < C; m++) moved[m] = (int)sc[4 * C + m];
     if (counters) for (int k = 0; k < 4; k++) counters[k] = (long)sc[5 * C + (size_t)k];
+    if (moves_per_chain) for (size_t m = 0; m < C; m++) moves_per_chain[m] = (long)sc[5 * C + 4 + m];
     return TAMCMC_OK;
 }
 
@@ -1890,8 +1907,8 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     }
     if (samples && !zc_smp) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats && !zc_st) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
-    if (s1_open) DCHK(hipStreamSynchronize(I.gst[1]));
-    DCHK(hipStreamSynchronize(st));
+    if (s1_open) DCHK(Impl::wait_stream(I.gst[1]));
+    DCHK(Impl::wait_stream(st));
     for (const auto &e : fused_ev) {
         float ms = 0;
         DCHK(hipEventElapsedTime(&ms, I.ev[e.first][0], I.ev[e.first][1]));

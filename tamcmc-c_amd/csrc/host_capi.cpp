@@ -24,6 +24,7 @@ struct tamcmc_sampler {
     std::unique_ptr<Model_def> cur, prop;
     std::unique_ptr<DevSampler> dev;  // engine 1: the iteration runs on the GPU, the host objects mirror its state
     long accepted0 = 0;
+    std::vector<int64_t> moves;     // per chain: iterations whose record carries moved = 1 (what the reference's acceptance diagnostic counts)
     tamcmc_hip_ctx *ctx = nullptr;  // borrowed
     bool attached = false;
     // engine 1: the host mirrors (cur, mala's proposal law) are refreshed from the device only when somebody looks at them
@@ -42,9 +43,11 @@ int tamcmc_sampler::sync_from_device(bool proposal_too) {
     const long Nc = cfg.MALA.Nchains;
     std::vector<int> moved((size_t)Nc);
     long counters[4];
+    std::vector<long> mv((size_t)Nc);
     int rc = dev->download_state(cur->vars.a.data(), cur->params.a.data(), cur->logLikelihood.data(), cur->logPrior.data(),
-                                 cur->logPosterior.data(), cur->Pmove.data(), moved.data(), counters);
+                                 cur->logPosterior.data(), cur->Pmove.data(), moved.data(), counters, mv.data());
     if (rc) return rc;
+    moves.assign(mv.begin(), mv.end());
     for (long m = 0; m < Nc; m++) cur->moved[(size_t)m] = (char)moved[(size_t)m];
     accepted0 = counters[1];
     mala->Nswap_attempts = counters[2];
@@ -111,6 +114,7 @@ int tamcmc_sampler_create(tamcmc_sampler **out, tamcmc_hip_ctx *ctx, const tamcm
     g.MALA.fd_step_rel = c->fd_step_rel > 0 ? c->fd_step_rel : 1e-7;
     g.MALA.swap_rule = c->swap_rule == 1 ? 1 : 0;
     s->mala = std::make_unique<MALA>(&g);
+    s->moves.assign((size_t)c->Nchains, 0);
     s->ctx = ctx;
     s->cur = std::make_unique<Model_def>(&g, s->mala->Tcoefs, false, ctx);
     if (s->cur->last_status != TAMCMC_OK) return s->cur->last_status;
@@ -193,6 +197,7 @@ int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, double *samples, doubl
         int rc = s->mala->step(s->cur.get(), s->prop.get(), &s->cfg.data.data, &s->cfg);
         if (rc) return rc;
         s->accepted0 += s->cur->moved[0] ? 1 : 0;
+        for (long m = 0; m < Nc; m++) s->moves[(size_t)m] += s->cur->moved[(size_t)m] ? 1 : 0;
         if (samples) std::memcpy(samples + (size_t)it * Nc * Nv, s->cur->vars.a.data(), (size_t)(Nc * Nv) * sizeof(double));
         if (stats)
             for (long m = 0; m < Nc; m++) {
@@ -275,6 +280,13 @@ int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL
         counters[2] = s->mala->Nswap_attempts;
         counters[3] = s->mala->Nswap_accepted;
     }
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_get_move_counts(const tamcmc_sampler *s, int64_t *moves) {
+    if (!s || !moves) return TAMCMC_ERR_BAD_ARG;
+    if (int rc = s->refresh()) return rc;
+    for (size_t m = 0; m < (size_t)s->cfg.MALA.Nchains; m++) moves[m] = m < s->moves.size() ? s->moves[m] : 0;
     return TAMCMC_OK;
 }
 

@@ -53,6 +53,66 @@ int64_t rows_on_disk(const std::string &file, size_t row_bytes) {
 
 extern "C" {
 
+// Outputs::write_txt_acceptance (outputs.cpp:747-790): `strg << xaxis; strg << " "; strg << acceptance_rate.transpose() << "\n"`.
+int tamcmc_outputs_write_acceptance(const char *file, double xaxis, const double *rates, int32_t Nchains, int32_t first) {
+    if (!file || !rates || Nchains < 1) return TAMCMC_ERR_BAD_ARG;
+    std::ofstream f;
+    if (first) f.open(file);
+    else f.open(file, std::ofstream::app);
+    if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
+    if (first) {
+        f << "# This is an output file for the acceptance rate. \n";
+        f << "# This file contains values for the acceptance_rate[0:Nchains-1] in function of the average sample position\n";
+        f << "# Averaging is done over Nbuffer \n";
+        f << "! Nchains= " << Nchains << "\n";
+    }
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.6g", xaxis);  // a double through an ostream with the default precision
+    f << buf << " " << eigen_row(rates, Nchains) << "\n";
+    f.flush();
+    return f.good() ? TAMCMC_OK : TAMCMC_ERR_BAD_ARG;
+}
+
+int tamcmc_outputs_read_acceptance(const char *file, int32_t *Nchains, int64_t max_rows, int64_t *n_rows, double *xaxis, double *rates) {
+    if (!file || !Nchains || !n_rows) return TAMCMC_ERR_BAD_ARG;
+    std::ifstream f(file);
+    if (!f.is_open()) return TAMCMC_ERR_BAD_ARG;
+    std::string ln;
+    int nc = -1;
+    int64_t n = 0;
+    while (std::getline(f, ln)) {
+        size_t p0 = ln.find_first_not_of(" \t\r");
+        if (p0 == std::string::npos || ln[p0] == '#') continue;
+        if (ln[p0] == '!') {
+            const size_t eq = ln.find('=');
+            if (eq == std::string::npos) return TAMCMC_ERR_BAD_ARG;
+            nc = std::atoi(ln.c_str() + eq + 1);
+            if (nc < 1) return TAMCMC_ERR_BAD_ARG;
+            continue;
+        }
+        if (nc < 1) return TAMCMC_ERR_BAD_ARG;  // a data line before the header
+        const char *q = ln.c_str() + p0;
+        char *e = nullptr;
+        const double x = std::strtod(q, &e);
+        if (e == q) return TAMCMC_ERR_BAD_ARG;
+        std::vector<double> r((size_t)nc);
+        for (int m = 0; m < nc; m++) {
+            q = e;
+            r[(size_t)m] = std::strtod(q, &e);
+            if (e == q) return TAMCMC_ERR_BAD_ARG;
+        }
+        if (n < max_rows) {
+            if (xaxis) xaxis[n] = x;
+            if (rates) std::memcpy(rates + (size_t)n * (size_t)nc, r.data(), (size_t)nc * sizeof(double));
+        }
+        n++;
+    }
+    if (nc < 1) return TAMCMC_ERR_BAD_ARG;
+    *Nchains = nc;
+    *n_rows = n;
+    return TAMCMC_OK;
+}
+
 // Outputs::write_bin_params (outputs.cpp:1231-1333).  Like the reference, the ASCII header is rewritten with EVERY buffer and carries
 // the cumulative sample count (outputs.cpp:1268: Nbuffer*Ncopy + counts + Nsamples_sofar) -- its tools read exactly Nsamples_done
 // rows (getstats.cpp:156, getevidence.cpp:197); append != 0 = a later buffer of the same run (the .bin files grow).

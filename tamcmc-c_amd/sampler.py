@@ -25,6 +25,9 @@ EXTRA_ABI += [
     ("tamcmc_sampler_destroy", None, [_vp]),
     ("tamcmc_sampler_nvars", C.c_int64, [_vp]),
     ("tamcmc_sampler_get_info", C.c_int, [_vp, _i64p, C.c_int32]),
+    ("tamcmc_sampler_get_move_counts", C.c_int, [_vp, _i64p]),
+    ("tamcmc_outputs_write_acceptance", C.c_int, [C.c_char_p, C.c_double, _dp, C.c_int32, C.c_int32]),
+    ("tamcmc_outputs_read_acceptance", C.c_int, [C.c_char_p, _ip, C.c_int64, _i64p, _dp, _dp]),
     ("tamcmc_sampler_run", C.c_int, [_vp, C.c_int64, _dp, _dp]),
     ("tamcmc_sampler_run_packed", C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int64, C.POINTER(_dp), C.POINTER(_dp)]),
     ("tamcmc_sampler_draws", C.c_int, [_vp, C.c_int64, _dp, _dp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -152,6 +155,14 @@ class Sampler:
         keys = ("engine", "nvars", "nparams", "nchains", "adapt_in_lds", "fused_available", "chain_groups", "iter_fused", "iter_lockstep")
         return dict(zip(keys, (int(x) for x in v)))
 
+    def move_counts(self):
+        """Per chain: iterations since creation whose record carries moved = 1 (tamcmc_sampler_get_move_counts)."""
+        v = np.zeros(self.nchains, dtype=np.int64)
+        rc = self._L.tamcmc_sampler_get_move_counts(self._h, _p(v, _i64p))
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_get_move_counts")
+        return v
+
     def draws(self, iteration):
         """The random numbers iteration `iteration` consumes: (z [Nchains x Nvars], u_accept [Nchains], u_swap, ind_A)."""
         z, u = np.zeros((self.nchains, self.nvars)), np.zeros(self.nchains)
@@ -246,6 +257,27 @@ def write_outputs(root, star, samples, stats=None, nsamples_total=None, append=F
         st = L.tamcmc_outputs_write_stat_criteria(str(root).encode(), _p(stt), stt.shape[0], nc, int(append))
         if st != OK:
             raise TamcmcError(st, "tamcmc_outputs_write_stat_criteria")
+
+
+def write_acceptance(file, xaxis, rates, first):
+    """One line of the reference's acceptance diagnostic file (Outputs::write_txt_acceptance)."""
+    L = _rebind()
+    r = _f64(rates)
+    rc = L.tamcmc_outputs_write_acceptance(str(file).encode(), float(xaxis), _p(r), r.size, int(bool(first)))
+    if rc != OK:
+        raise TamcmcError(rc, "tamcmc_outputs_write_acceptance")
+
+
+def read_acceptance(file):
+    """(xaxis [n], rates [n x Nchains]) of an acceptance diagnostic file."""
+    L = _rebind()
+    nc, n = C.c_int32(0), C.c_int64(0)
+    rc = L.tamcmc_outputs_read_acceptance(str(file).encode(), C.byref(nc), 0, C.byref(n), None, None)
+    if rc != OK:
+        raise TamcmcError(rc, "tamcmc_outputs_read_acceptance")
+    x, r = np.zeros(n.value), np.zeros((n.value, nc.value))
+    L.tamcmc_outputs_read_acceptance(str(file).encode(), C.byref(nc), n.value, C.byref(n), _p(x), _p(r))
+    return x, r
 
 
 def read_params(root, chain):

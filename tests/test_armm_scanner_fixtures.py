@@ -129,4 +129,4 @@ def test_device_prestep_reproduces_the_reference_solver_outputs(pkg, oracle, syn
             assert printed_equal(h, d["H1/H0"][keep]), (name, np.max(np.abs(h - d["H1/H0"][keep])))
             rc, md = oracle.rgb_modes(params, plength, x[2] - x[1], cte_width=model_cte)
             assert rc == 0 and md["fl1"].size == nu.size
-            assert np.max(np.abs(nu - md["fl1"])) < 1e-7 and np.max(np.abs(z - md["ksi"])) < 1e-7
+            assert np.max(np.abs(nu - md["fl1"])) < 1e-10 and np.max(np.abs(z - md["ksi"])) < 1e-10   # (muHz; red-giant tolerance, include/tamcmc_hip.h)

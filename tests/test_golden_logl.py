@@ -48,10 +48,10 @@ def test_device_matches_the_golden_numbers(pkg, i):
         assert st[0] == 0
         return m[0]
     x, y, P, pl, m0 = _inputs(c, row0)
-    rgb = c["model_id"] == 25          # its mixed-mode frequencies come from device tan/atan: ~1e-8 on the row, see test_gpu_rgb.py
-    assert np.allclose(m0[c["model_bins"]], c["model_row0"], rtol=1e-6 if rgb else 1e-13), c["name"]
+    rgb = c["model_id"] == 25          # its mixed-mode frequencies come from device tan/atan: red-giant tolerance, see test_gpu_rgb.py
+    assert np.allclose(m0[c["model_bins"]], c["model_row0"], rtol=1e-9 if rgb else 1e-13), c["name"]
     # the spectrum is built from the DEVICE's own STRICT row (bit-identical to the oracle's for the main-sequence models)
-    for prec, tol in ((pkg.PRECISION_STRICT, 1e-7 if rgb else 1e-12), (pkg.PRECISION_FAST, 1e-7 if rgb else 1e-11)):
+    for prec, tol in ((pkg.PRECISION_STRICT, 1e-11 if rgb else 1e-12), (pkg.PRECISION_FAST, 1e-11)):
         ctx.set_option(pkg.OPT_PRECISION, prec)
         ctx.set_spectrum(x, y)
         logL, _, st = ctx.loglike_params_batch(c["model_id"], P, pl, np.array(c["T"]))

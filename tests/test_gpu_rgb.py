@@ -28,13 +28,15 @@ def test_rgb_model_rows_and_logl_match_the_oracle(pkg, oracle, synth, bias_type,
         P[1:, o[7]] *= 1 + 0.1 * rng.standard_normal(B - 1)                          # the one width
     ref, m_o, st_o = oracle.loglike_batch(model_id, P, pl, x, y, 1.0, T, want_model=True)
     assert (st_o == 0).all()
-    for prec, tol_m, tol_l in ((pkg.PRECISION_STRICT, 1e-7, 1e-8), (pkg.PRECISION_FAST, 1e-7, 1e-8)):
+    for prec, tol_m, tol_l in ((pkg.PRECISION_STRICT, 1e-10, 1e-12), (pkg.PRECISION_FAST, 1e-10, 1e-12)):
         ctx = pkg.HipContext(0, precision=prec)
         ctx.set_spectrum(x, y)
         got, m_d, st_d = ctx.loglike_params_batch(model_id, P, pl, T, want_model=True)
         assert (st_d == 0).all()
-        # same mixed modes (a missing or extra mode would change the row by O(1) around it); frequencies agree to ~1e-10 muHz
-        # (device tan/atan in double vs the reference's long double), i.e. ~1e-8 relative on a 0.05 muHz-wide profile
+        # same mixed modes (a missing or extra mode would change the row by O(1) around it).  Stated red-giant tolerance
+        # (include/tamcmc_hip.h): rows ||dM||_2 / ||M||_2 <= 1e-10, logL 1e-12 relative.  Measured on the MI355X (tools/rgb_parity_probe.py,
+        # round 3): mixed-mode frequencies within 3e-13 muHz of the oracle's (1.5e-11 at the 2e5-bin C5 size), zeta within 4e-13, rows
+        # 2e-13 (1e-11 at C5), logL 3e-15 -- the device's double tan / atan against the long double of solver_mm.cpp:179-186
         rel = np.linalg.norm(m_d - m_o, axis=1) / np.linalg.norm(m_o, axis=1)
         assert rel.max() < tol_m, rel
         assert np.allclose(got, ref, rtol=tol_l, atol=0), np.abs(got / ref - 1).max()
@@ -74,7 +76,7 @@ def test_rgb_star_samples_on_the_host_engine(pkg, oracle, synth, cte):
     st0 = s.state()
     T = 1.6 ** np.arange(4)
     ref, _, so = oracle.loglike_batch(star.model_id, np.tile(star.params, (4, 1)), star.plength, star.x, star.y, 1.0, T)
-    assert (so == 0).all() and np.allclose(st0["logL"], ref, rtol=1e-8) and np.isfinite(st0["logPrior"]).all()
+    assert (so == 0).all() and np.allclose(st0["logL"], ref, rtol=1e-11) and np.isfinite(st0["logPrior"]).all()
     smp, stat = s.run(150, stats=True)
     assert np.isfinite(stat).all() and s.state()["iteration"] == 150
     assert (smp[:, 0] != smp[0, 0]).any() and s.state()["swap_attempts"] == 149
@@ -115,7 +117,7 @@ def test_rgb_device_engine_follows_the_host_engine(pkg, oracle, synth, cte, lear
     held = np.tile(star.params, (5, 1))
     held[:, star.index_to_relax] = b["vars"]
     ref, _, so = oracle.loglike_batch(star.model_id, held, star.plength, star.x, star.y, 1.0, T)
-    assert (so == 0).all() and np.allclose(b["logL"], ref, rtol=1e-7)
+    assert (so == 0).all() and np.allclose(b["logL"], ref, rtol=1e-10), np.abs(b["logL"] / ref - 1).max()
     h.close(); d.close(); ctx.close()
 
 
@@ -138,7 +140,7 @@ def test_rgb_device_engine_rejects_vectors_the_prestep_refuses(pkg, oracle, synt
     held = np.tile(star.params, (3, 1))
     held[:, star.index_to_relax] = stt["vars"]
     ref, _, so = oracle.loglike_batch(star.model_id, held, star.plength, star.x, star.y, 1.0, 2.0 ** np.arange(3))
-    assert (so == 0).all() and np.allclose(stt["logL"], ref, rtol=1e-7)
+    assert (so == 0).all() and np.allclose(stt["logL"], ref, rtol=1e-10), np.abs(stt["logL"] / ref - 1).max()
     d.close(); ctx.close()
 
 
@@ -194,11 +196,11 @@ def test_real_red_giant_from_the_reference_files(pkg, oracle):
     got, m_d, st_d = ctx.loglike_params_batch(star.model_id, P, star.plength, T, want_model=True)
     assert (st_o == 0).all() and (st_d == 0).all()
     rel = np.linalg.norm(m_d - m_o, axis=1) / np.linalg.norm(m_o, axis=1)
-    assert rel.max() < 1e-7, rel
-    assert np.allclose(got, ref, rtol=1e-8, atol=0), np.abs(got / ref - 1).max()
+    assert rel.max() < 1e-10, rel
+    assert np.allclose(got, ref, rtol=1e-11, atol=0), np.abs(got / ref - 1).max()
     s = pkg.Sampler(ctx, star, nchains=4, lambda_temp=1.5, seed=11, engine="host", Nt_learn=(20, 150), periods_learn=(1,))
     st0 = s.state()
-    assert np.allclose(st0["logL"], ref[0] * T[0] / T, rtol=1e-8) and np.isfinite(st0["logPrior"]).all()
+    assert np.allclose(st0["logL"], ref[0] * T[0] / T, rtol=1e-11) and np.isfinite(st0["logPrior"]).all()
     smp, stat = s.run(160, stats=True)
     assert np.isfinite(stat).all() and (smp[:, 0] != smp[0, 0]).any() and s.state()["swap_attempts"] == 159
     assert stat[-40:, 0, 2].mean() > st0["logPost"][0] - 40.0
@@ -244,8 +246,8 @@ def test_rgb_awkward_stars_match_the_oracle(pkg, oracle, synth, case):
     ok = st_o == 0
     assert ok.any()
     rel = np.linalg.norm(m_d[ok] - m_o[ok], axis=1) / np.linalg.norm(m_o[ok], axis=1)
-    assert rel.max() < 1e-7, rel
-    assert np.allclose(got[ok], ref[ok], rtol=1e-8, atol=0), np.abs(got[ok] / ref[ok] - 1).max()
+    assert rel.max() < 1e-10, rel
+    assert np.allclose(got[ok], ref[ok], rtol=1e-12, atol=0), np.abs(got[ok] / ref[ok] - 1).max()
     ctx.close()
 
 
@@ -266,5 +268,5 @@ def test_rgb_full_size_c5_matches_the_oracle(pkg, oracle, synth):
     ctx.set_spectrum(star.x, y)
     got, _, st_d = ctx.loglike_params_batch(star.model_id, P, star.plength, T)
     assert (st_o == 0).all() and (st_d == 0).all()
-    assert np.allclose(got, ref, rtol=1e-10, atol=0), np.abs(got / ref - 1).max()
+    assert np.allclose(got, ref, rtol=1e-12, atol=0), np.abs(got / ref - 1).max()
     ctx.close()

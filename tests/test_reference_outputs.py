@@ -162,3 +162,24 @@ def test_evidence_known_answers_from_the_reference_run(pkg, oracle, tmp_path):
         L = S._rebind()
         assert L.tamcmc_outputs_write_evidence(str(out).encode(), int(r[0]), 4, S._p(beta), S._p(Lb), k, r[5], int(i == 0)) == 0
     assert open(out).read() == open(os.path.join(GOLD, "10280410_Gaussfit_A_evidence.txt")).read()
+
+
+def test_acceptance_file_of_a_finished_run(pkg, tmp_path):
+    """`10280410_Gaussfit_A_acceptance.txt`: the acceptance diagnostic the reference appends one line to per buffer
+    (Outputs::write_txt_acceptance, outputs.cpp:747-790; x = (Ncopy + 0.5) Nbuffer + Nsamples_init, :1838; rates = moved flags of the
+    buffer / Nbuffer, :1834-1837).  The reader returns the printed numbers; the writer, fed with them, reproduces the file byte for
+    byte (header, Eigen's padding of the rate columns to the widest entry); the x axis is the one reject_rate builds."""
+    from tamcmc_c_amd import sampler as S
+    src = os.path.join(GOLD, "10280410_Gaussfit_A_acceptance.txt")
+    x, r = S.read_acceptance(src)
+    assert r.shape == (20, 4) and x[0] == 2500 and x[-1] == 97500
+    assert np.array_equal(r[0], [0.237, 0.2316, 0.2764, 0.2348]) and np.array_equal(r[9], [0.2384, 0.2268, 0.26, 0.2384])
+    Nbuffer = 5000
+    assert np.array_equal(x, (np.arange(20) + 0.5) * Nbuffer + 0)                      # outputs.cpp:1838 with Nsamples_init = 0
+    assert np.all((r * Nbuffer - np.round(r * Nbuffer)) ** 2 < 1e-12)                   # counts of moved flags over the buffer length
+    out = str(tmp_path / "acc.txt")
+    for k in range(20):
+        S.write_acceptance(out, x[k], r[k], first=(k == 0))
+    assert open(out, "rb").read() == open(src, "rb").read()
+    # coldest chain at the target of the adaptation (config_default.cfg: 0.234) as the finished run left it
+    assert abs(r[:, 0].mean() - 0.234) < 0.01
