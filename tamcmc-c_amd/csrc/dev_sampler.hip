@@ -27,6 +27,7 @@
 // chains' state in the same arrays; a stretch hands over to the next with the parity only.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <hip/hip_ext.h>
 
@@ -1238,9 +1239,11 @@ struct DevSampler::Impl {
     // End of a call: the host waits for a stream by polling it for up to a millisecond before it blocks.  A blocking wait parks the
     // thread on an interrupt and wakes tens of microseconds after the last kernel has finished -- a tenth of a 20-iteration call (the
     // reference writes its ring buffer every Nbuffer iterations; a caller with short buffers makes short calls).
-    static hipError_t wait_stream(hipStream_t st) {
+    // (only when this is the process's one running call: several host threads polling -- co-resident stars, tamcmc_sampler_run_packed --
+    // would contend for the runtime's locks with the threads that are still enqueuing)
+    static hipError_t wait_stream(hipStream_t st, bool poll) {
         const auto t0 = std::chrono::steady_clock::now();
-        for (int spin = 0;; spin++) {
+        for (int spin = 0; poll; spin++) {
             const hipError_t e = hipStreamQuery(st);
             if (e != hipErrorNotReady) return e;
             if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) break;
@@ -1558,7 +1561,14 @@ int DevSampler::download_proposal(int m, double *cov, double *mu, double *sigma)
 
 // n_iter iterations starting at iteration counter `it0`; learn[i] != 0 -> adaptation after iteration it0+i.
 // Stretches without adaptation run as fused steps (A), the others in lockstep (B); see the head of this file.
+static std::atomic<int> g_running_calls{0};
+struct RunningCall {
+    RunningCall() { g_running_calls.fetch_add(1, std::memory_order_relaxed); }
+    ~RunningCall() { g_running_calls.fetch_sub(1, std::memory_order_relaxed); }
+};
+
 int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, double *stats) {
+    RunningCall running_call;
     Impl &I = *impl;
     tamcmc_hip_ctx *c = I.ctx;
     DevSamplerArgs &a = I.a;
@@ -1907,8 +1917,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     }
     if (samples && !zc_smp) DCHK(hipMemcpyAsync(samples, a.samples, (size_t)n_iter * C * Nv * 8, hipMemcpyDeviceToHost, st));
     if (stats && !zc_st) DCHK(hipMemcpyAsync(stats, a.stats, (size_t)n_iter * C * 3 * 8, hipMemcpyDeviceToHost, st));
-    if (s1_open) DCHK(Impl::wait_stream(I.gst[1]));
-    DCHK(Impl::wait_stream(st));
+    const bool poll = g_running_calls.load(std::memory_order_relaxed) == 1;
+    if (s1_open) DCHK(Impl::wait_stream(I.gst[1], poll));
+    DCHK(Impl::wait_stream(st, poll));
     for (const auto &e : fused_ev) {
         float ms = 0;
         DCHK(hipEventElapsedTime(&ms, I.ev[e.first][0], I.ev[e.first][1]));
