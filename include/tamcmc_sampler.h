@@ -117,6 +117,17 @@ int tamcmc_sampler_draws(const tamcmc_sampler *s, int64_t iteration, double *z, 
  *   of chain 0, swap attempts, swaps accepted */
 int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL, double *logPrior, double *logPost,
                              double *Pmove, double *sigma, int64_t *counters);
+/* use_drift = 1: the gradient of the tempered log-posterior the sampler HOLDS for each chain's current position -- computed when that
+ * position was proposed, carried through the accept step and, after a parallel-tempering swap, moved to the partner with its likelihood
+ * share re-tempered (grad_prior = the prior's share).  grad / grad_prior [Nchains x Nvars], valid [Nchains] (0: will be recomputed before
+ * its next use: start of a run, positions set from outside); any pointer may be NULL.  An audit entry like tamcmc_sampler_draws. */
+int tamcmc_sampler_get_gradient(const tamcmc_sampler *s, double *grad, double *grad_prior, int32_t *valid);
+/* What the LAST iteration tested -- the proposals vars_prop [Nchains x Nvars], their logL (tempered) / logPrior / logPosterior
+ * stats_prop [Nchains x 3] and, with use_drift = 1, lq [Nchains x 2] = log q(x'|x), log q(x|x') without the constant the two share,
+ * and grad_prop [Nchains x Nvars] = the gradient at the proposals.  Audit entry (tests replay an iteration piece by piece); any
+ * pointer may be NULL.  Host-driven engine: everything.  Device-resident engine: use_drift = 1 only (else TAMCMC_ERR_BAD_ARG),
+ * vars_prop and grad_prop; stats_prop and lq come back as NaN (those scalars are not kept). */
+int tamcmc_sampler_get_last_test(const tamcmc_sampler *s, double *vars_prop, double *stats_prop, double *lq, double *grad_prop);
 /* moves [Nchains]: for every chain the number of iterations since creation whose record carries moved = 1 -- the flag the reference
  * stores per iteration and chain (MALA.cpp:543-545; a swap exchanges the pair's flags, :436, :446) and its acceptance diagnostic counts
  * per buffer (Outputs::reject_rate / count_accepted_vals, outputs.cpp:1824-1858).  Differences between two calls / the iterations in

@@ -371,11 +371,16 @@ void orc_langevin_drift(const double *covarmat, double sigma, double epsi2, doub
  * fd_step_rel (steps h_k = fd_step_rel max(|mu_0k|, 1e-3) from chain 0's running mean BEFORE this iteration's adaptation -- the product's
  * rule, include/tamcmc_sampler.h), delta (drift truncation), diag (may be NULL) [Nchains x 4] = log q(x'|x), log q(x|x'), |drift(x)|, |drift(x')|,
  * chain_mask (may be NULL) [Nchains]: only the flagged chains are advanced (a check of a few chains of a large ladder; the caller flags
- * the swap pair, and compares the flagged chains only). */
+ * the swap pair, and compares the flagged chains only), prop_given (may be NULL) [Nchains x Nvars]: the test is made AT these proposals
+ * instead of the oracle's own (which are still returned in prop_vars).  Why: the model is truncated to windows of whole bins
+ * (build_lorentzian.cpp:595-676), so the log-likelihood -- hence its forward-difference gradient -- jumps where a window edge crosses a
+ * bin; when the step h_k moves an edge across a bin boundary (probability ~ h_k / bin width per edge) that gradient component carries
+ * (one bin's likelihood term) / h_k.  Two proposals that agree to rounding can sit on either side of such a jump and then have different
+ * drifts; handing the oracle the product's proposal (checked against its own to rounding) keeps the comparison on one side. */
 int orc_langevin_iteration(const orc_sampler_star *S, long i, int learn, int do_swap, int ind_A, double u_swap, int literal_444, const double *z,
                            const double *u_mh, double fd_step_rel, double delta, double *params, double *vars, double *logL, double *logPrior,
                            double *logPost, int *moved, double *Pmove, double *mu, double *covarmat, double *sigma, int *swapped,
-                           double *prop_vars, double *prop_stats, double *diag, const int *chain_mask) {
+                           double *prop_vars, double *prop_stats, double *diag, const int *chain_mask, const double *prop_given) {
     const long C = S->Nchains, Nv = S->Nvars, Np = S->Nparams;
     const long double gamma = (long double)S->c0 / (1. + i);
     double *h = (double *)malloc((size_t)Nv * sizeof(double));
@@ -397,11 +402,12 @@ int orc_langevin_iteration(const orc_sampler_star *S, long i, int learn, int do_
         /* x' = x + drift + L z */
         for (long k = 0; k < Nv; k++) mean[k] = x[k] + d0[k];
         orc_new_prop_values(cov, sigma[m], S->epsi2, mean, z + (size_t)m * Nv, Nv, v_new, NULL);
+        if (prop_vars) memcpy(prop_vars + (size_t)m * Nv, v_new, (size_t)Nv * sizeof(double));   /* the oracle's own proposal, always */
+        if (prop_given) memcpy(v_new, prop_given + (size_t)m * Nv, (size_t)Nv * sizeof(double)); /* ... tested at the caller's (see the header) */
         memcpy(p_new, params + (size_t)m * Np, (size_t)Np * sizeof(double));
         for (long k = 0; k < Nv; k++) p_new[S->index_to_relax[k]] = v_new[k];
         double l, pr, po, r;
         orc_generate_model(S, p_new, S->Tcoefs[m], S->init_logL[m], model, &l, &pr, &po);
-        if (prop_vars) memcpy(prop_vars + (size_t)m * Nv, v_new, (size_t)Nv * sizeof(double));
         if (prop_stats) { prop_stats[3 * m] = l; prop_stats[3 * m + 1] = pr; prop_stats[3 * m + 2] = po; }
         long double lq_fwd = 0, lq_rev = 0;
         double nd1 = 0;

@@ -199,7 +199,7 @@ void orc_langevin_drift(const double *covarmat, double sigma, double epsi2, doub
 int orc_langevin_iteration(const orc_sampler_star *S, long i, int learn, int do_swap, int ind_A, double u_swap, int literal_444, const double *z,
                            const double *u_mh, double fd_step_rel, double delta, double *params, double *vars, double *logL, double *logPrior,
                            double *logPost, int *moved, double *Pmove, double *mu, double *covarmat, double *sigma, int *swapped,
-                           double *prop_vars, double *prop_stats, double *diag, const int *chain_mask);
+                           double *prop_vars, double *prop_stats, double *diag, const int *chain_mask, const double *prop_given);
 
 #ifdef __cplusplus
 }

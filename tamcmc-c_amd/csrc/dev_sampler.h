@@ -78,6 +78,8 @@ class DevSampler {
     int download_state(double *vars, double *params, double *logL, double *logPr, double *logPost, double *Pmove,
                        int *moved, long *counters, long *moves_per_chain = nullptr);
     int download_proposal(int m, double *cov, double *mu, double *sigma);
+    int download_gradient(double *grad, double *grad_prior);
+    int download_last_proposal(double *vars_prop, double *grad_prop);  // use_drift: what the last iteration tested  // use_drift: [C x Nv] gradient the engine holds for the chains' positions
     // [0] Nvars [1] Nparams [2] adaptation workspace in LDS (1) / global scratch (0) [3] fused step available [4] chain groups
     // [5] iterations run fused [6] iterations run by the lockstep kernels [7] chains
     void info(long out[8]) const;

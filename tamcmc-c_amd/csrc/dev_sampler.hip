@@ -301,7 +301,8 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
     // Cholesky in place (lower triangle of A).  A matrix that is not positive definite (possible only while gamma = c0/(1+i) > 1,
     // i.e. adaptation before iteration c0) keeps the PREVIOUS factor -- the host engine does the same (host_mala.cpp::factor); the
     // reference hands Eigen's partial result on.  Every element sees the operations of the right-looking algorithm in its order
-    // (A_ik -= L_ij L_kj for j ascending, then / d_kk), so the factor is the host engine's bit for bit -- only the schedule differs:
+    // (A_ik -= L_ij L_kj for j ascending, then scaled by 1/d_kk), the host engine's factor to 1-2 ulp (round 3: reciprocal square roots
+    // in the panels' diagonal blocks; the sqrt / divide sequence of the host engine was the factorisation's serial chain):
     //   * panels of NB columns: the NB x NB diagonal block is factored by NB lanes of one wave (rows in registers, pivots by
     //     shuffles, no workgroup barrier inside); the panel's columns below it are one forward substitution per row, a row per lane;
     //     then all lanes apply the NB columns to the trailing block in one sweep (a 16 x 16 grid over rows x columns, L_i,panel in
@@ -329,9 +330,16 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
                     const double ajj = lane_value<jj>(r[jj]);
                     if (!(ajj > 0.0)) bad = true;
                     else {
-                        const double djj = sqrt(ajj);
-                        if (tid > jj) r[jj] = r[jj] / djj;
-                        else if (tid == jj) r[jj] = djj;
+                        // 1/sqrt(a_jj): v_rsq_f64 seed + two Newton steps (the serial chain of the factorisation is this step, once per
+                        // column: an IEEE sqrt followed by an IEEE divide is ~5x as long); the column is scaled by it, the diagonal is
+                        // a_jj / sqrt(a_jj) with one correction step.  1-2 ulp from the sqrt / divide factor of the host engine
+                        double y = __builtin_amdgcn_rsq(ajj);
+                        y = fma(y, fma(-ajj * y, 0.5 * y, 0.5), y);
+                        y = fma(y, fma(-ajj * y, 0.5 * y, 0.5), y);
+                        double djj = ajj * y;
+                        djj = fma(fma(-djj, djj, ajj), 0.5 * y, djj);
+                        if (tid > jj) r[jj] = r[jj] * y;
+                        else if (tid == jj) { r[jj] = djj; d[p0 + jj] = y; }  // (d[] is free since the covariance update: reciprocal pivots)
                         static_for<NB - 1 - jj>([&](auto kc) {
                             constexpr int kk = jj + 1 + decltype(kc)::value;
                             const double lk = lane_value<kk>(r[jj]);  // L_(p0+kk),jj
@@ -355,10 +363,11 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
                 static_for<NB>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
                     li[c] = A[(size_t)i * Nv + p0 + c];
-                    static_for<c + 1>([&](auto qc) {
+                    static_for<c>([&](auto qc) {
                         constexpr int q = decltype(qc)::value;
                         Ld[c][q] = A[(size_t)(p0 + c) * Nv + p0 + q];
                     });
+                    Ld[c][c] = d[p0 + c];  // reciprocal pivot (diag_block)
                 });
                 static_for<NB>([&](auto jc) {
                     constexpr int jj = decltype(jc)::value;
@@ -366,7 +375,7 @@ __device__ void adapt_chain_as(const DevSamplerArgs &a, int m, long itp, const d
                         constexpr int q = decltype(qc)::value;
                         li[jj] = li[jj] - li[q] * Ld[jj][q];
                     });
-                    li[jj] = li[jj] / Ld[jj][jj];
+                    li[jj] = li[jj] * Ld[jj][jj];
                 });
                 static_for<NB>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
@@ -1431,6 +1440,30 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     return TAMCMC_OK;
 }
 
+int DevSampler::download_gradient(double *grad, double *grad_prior) {
+    Impl &I = *impl;
+    tamcmc_hip_ctx *c = I.ctx;
+    if (!I.use_drift || !I.a.grad_cur || !I.grad_valid) return TAMCMC_ERR_BAD_ARG;
+    DCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)I.a.C * I.a.Nv;
+    DCHK(hipStreamSynchronize(c->stream));
+    if (grad) DCHK(hipMemcpy(grad, I.a.grad_cur + (size_t)I.parity * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (grad_prior) DCHK(hipMemcpy(grad_prior, I.a.gradP_cur + (size_t)I.parity * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    return TAMCMC_OK;
+}
+
+int DevSampler::download_last_proposal(double *vars_prop, double *grad_prop) {
+    Impl &I = *impl;
+    tamcmc_hip_ctx *c = I.ctx;
+    if (!I.use_drift) return TAMCMC_ERR_BAD_ARG;  // (the random-walk schemes keep several candidate proposals per chain, not one)
+    DCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)I.a.C * I.a.Nv;
+    DCHK(hipStreamSynchronize(c->stream));
+    if (vars_prop) DCHK(hipMemcpy(vars_prop, I.a.vars_prop, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (grad_prop) DCHK(hipMemcpy(grad_prop, I.mala.grad_prop, n * sizeof(double), hipMemcpyDeviceToHost));
+    return TAMCMC_OK;
+}
+
 void DevSampler::info(long out[8]) const {
     const Impl &I = *impl;
     out[0] = I.a.Nv; out[1] = I.a.desc.Np;
@@ -1976,7 +2009,7 @@ int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *sampl
             DCHK(hipStreamSynchronize(st));
             DCHK(I.fd_part.reserve(nb.nS * (size_t)nb.ntiles * 2));
             DCHK(I.fd_S.reserve(nb.nS));
-            if (nb.windowed) DCHK(I.fd_model.reserve(C * (size_t)c->Nx));
+            if (nb.windowed) DCHK(I.fd_model.reserve(2 * C * (size_t)c->Nx));  // two planes: 1/M0, y/M0 of the base points
             if (c->precision == TAMCMC_PRECISION_FAST) DCHK(I.fd_bg.reserve((size_t)(nb.windowed ? a.C : nb.B) * nb.ntiles * 8));
             I.grad_valid = false;
         }

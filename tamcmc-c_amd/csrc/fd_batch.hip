@@ -280,7 +280,7 @@ int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_param
         // (1) the C base points: full evaluation, model rows kept
         a.B = C;
         a.mults = fa.T.mults; a.offsets = fa.Bs.pairs; a.noise = fa.Bs.noise; a.nharvey = fa.Bs.nh; a.nnoise = fa.Bs.nn;
-        a.partials = part; a.model = model;
+        a.partials = part; a.model = model; a.fd_rows = model; a.fd_plane = (size_t)C * Nx;  // (1/M0 and y/M0 planes instead of the rows)
         if (c->precision == TAMCMC_PRECISION_FAST) {
             HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, bgbuf, st));
             a.bg_poly = bgbuf;
@@ -289,7 +289,7 @@ int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_param
         HIPCHK(c, launch_finalize(part, C, ntiles, S, st));
         // (2) the C*Nvars perturbed points: log-likelihood DIFFERENCES from the delta tables
         LoglikeArgs d = a;
-        d.B = B; d.model = nullptr; d.bg_poly = nullptr;
+        d.B = B; d.model = nullptr; d.fd_rows = nullptr; d.bg_poly = nullptr;
         d.mults = fa.D.mults; d.offsets = fa.D.pairs; d.noise = fa.D.noise; d.nharvey = fa.D.nh; d.nnoise = fa.D.nn;
         d.partials = part + (size_t)C * ntiles * 2;
         d.d_range = fa.d_range; d.d_flags = fa.d_flags; d.d_row = fa.d_row; d.d_noise_old = fa.d_noise_old; d.model0 = model;
@@ -354,7 +354,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     HIPCHK(c, c->d_part.reserve(nS * fb.ntiles * 2));
     HIPCHK(c, c->d_S.reserve(nS));
     HIPCHK(c, c->h_S.reserve(nS));
-    if (windowed) HIPCHK(c, c->d_model.reserve((size_t)C * c->Nx));
+    if (windowed) HIPCHK(c, c->d_model.reserve(2 * (size_t)C * c->Nx));  // two planes: 1/M0, y/M0
     if (c->precision == TAMCMC_PRECISION_FAST) HIPCHK(c, c->d_bg.reserve((size_t)(windowed ? C : B) * fb.ntiles * 8));
     rc = fb.enqueue(c, db, nullptr, c->d_part.p, c->d_S.p, c->d_model.p, c->d_bg.p, c->timing ? c->ev0 : nullptr, c->timing ? c->ev1 : nullptr);
     if (rc) return rc;

@@ -283,6 +283,45 @@ int tamcmc_sampler_get_state(const tamcmc_sampler *s, double *vars, double *logL
     return TAMCMC_OK;
 }
 
+int tamcmc_sampler_get_gradient(const tamcmc_sampler *s, double *grad, double *grad_prior, int32_t *valid) {
+    if (!s || !s->cfg.MALA.use_drift) return TAMCMC_ERR_BAD_ARG;
+    const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    if (s->dev) {
+        const int rc = s->dev->download_gradient(grad, grad_prior);
+        if (valid) for (long m = 0; m < Nc; m++) valid[m] = rc == TAMCMC_OK ? 1 : 0;
+        return TAMCMC_OK;  // (no gradient yet: every chain flagged invalid)
+    }
+    for (long m = 0; m < Nc; m++) {
+        if (valid) valid[m] = s->mala->gradient_valid((int)m) ? 1 : 0;
+        if (grad) std::memcpy(grad + (size_t)m * Nv, s->mala->held_gradient((int)m), (size_t)Nv * sizeof(double));
+        if (grad_prior) std::memcpy(grad_prior + (size_t)m * Nv, s->mala->held_gradient_prior((int)m), (size_t)Nv * sizeof(double));
+    }
+    return TAMCMC_OK;
+}
+
+int tamcmc_sampler_get_last_test(const tamcmc_sampler *s, double *vars_prop, double *stats_prop, double *lq, double *grad_prop) {
+    if (!s) return TAMCMC_ERR_BAD_ARG;
+    const long Nc = s->cfg.MALA.Nchains, Nv = s->cur->get_Nvars();
+    if (s->dev) {  // device-resident Langevin engine: the proposals and their gradients; the scalars stay on the device (NaN here)
+        for (long m = 0; m < Nc; m++) {
+            if (stats_prop) stats_prop[3 * m] = stats_prop[3 * m + 1] = stats_prop[3 * m + 2] = NAN;
+            if (lq) lq[2 * m] = lq[2 * m + 1] = NAN;
+        }
+        return s->dev->download_last_proposal(vars_prop, grad_prop);
+    }
+    for (long m = 0; m < Nc; m++) {
+        if (vars_prop) std::memcpy(vars_prop + (size_t)m * Nv, s->prop->vars.row(m), (size_t)Nv * sizeof(double));
+        if (stats_prop) {
+            stats_prop[3 * m] = s->prop->logLikelihood[(size_t)m];
+            stats_prop[3 * m + 1] = s->prop->logPrior[(size_t)m];
+            stats_prop[3 * m + 2] = s->prop->logPosterior[(size_t)m];
+        }
+        if (lq) { lq[2 * m] = s->mala->last_lq_fwd[(size_t)m]; lq[2 * m + 1] = s->mala->last_lq_rev[(size_t)m]; }
+        if (grad_prop && s->cfg.MALA.use_drift) std::memcpy(grad_prop + (size_t)m * Nv, s->mala->proposal_gradient((int)m), (size_t)Nv * sizeof(double));
+    }
+    return TAMCMC_OK;
+}
+
 int tamcmc_sampler_get_move_counts(const tamcmc_sampler *s, int64_t *moves) {
     if (!s || !moves) return TAMCMC_ERR_BAD_ARG;
     if (int rc = s->refresh()) return rc;

@@ -74,6 +74,8 @@ MALA::MALA(Config *cfg) {
     gradP_cur = Matrix(Nchains, Nvars);
     gradP_prop = Matrix(Nchains, Nvars);
     grad_valid.assign((size_t)Nchains, 0);
+    last_lq_fwd.assign((size_t)Nchains, 0.0);
+    last_lq_rev.assign((size_t)Nchains, 0.0);
 }
 
 // MALA.cpp:246-293: diagonal covariance from errors_default.cfg (error = value*fraction + offset, default 1),
@@ -374,6 +376,8 @@ int MALA::step(Model_def *cur, Model_def *prop, Data *data, Config *) {
                     const std::vector<double> drift_prop = D_MALA(grad_prop.row(m), (int)m);
                     lq_fwd = multinormal_logpdf(d.data(), drift_cur[(size_t)m].data(), (int)m);   // log q(x'|x)
                     lq_rev = multinormal_logpdf(dr.data(), drift_prop.data(), (int)m);            // log q(x|x')
+                    last_lq_fwd[(size_t)m] = (double)lq_fwd;
+                    last_lq_rev[(size_t)m] = (double)lq_rev;
                 }
                 const double e = std::exp((double)((long double)prop->logPosterior[(size_t)m] - cur->logPosterior[(size_t)m] +
                                                    lq_rev - lq_fwd));

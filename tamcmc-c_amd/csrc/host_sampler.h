@@ -178,6 +178,13 @@ class MALA {  // MALA.h:26-69
     bool learn_at(long i) const;  // MALA.cpp:656-667: is the proposal law updated after iteration i?
     uint64_t get_seed() const { return seed; }
     void invalidate(int m) { Lchol_valid[(size_t)m] = 0; grad_valid[(size_t)m] = 0; }
+    // the gradient held for chain m's position (tamcmc_sampler_get_gradient): rows of grad_cur / gradP_cur, and whether it is current
+    const double *held_gradient(int m) const { return grad_cur.a.data() + (size_t)m * (size_t)Nvars; }
+    const double *held_gradient_prior(int m) const { return gradP_cur.a.data() + (size_t)m * (size_t)Nvars; }
+    bool gradient_valid(int m) const { return grad_valid[(size_t)m] != 0; }
+    // audit of the last Langevin test (tamcmc_sampler_get_last_test): log q(x'|x), log q(x|x') up to their common constant
+    std::vector<double> last_lq_fwd, last_lq_rev;
+    const double *proposal_gradient(int m) const { return grad_prop.a.data() + (size_t)m * (size_t)Nvars; }
 };
 
 }  // namespace tamcmc

@@ -42,8 +42,12 @@ struct LoglikeArgs {
     const int32_t *d_range = nullptr;     // [2B] affected bin range [lo, hi) of evaluation b
     const int32_t *d_flags = nullptr;     // [B]  bit 0: the noise parameters changed (background difference on every bin)
     const double *d_noise_old = nullptr;  // [B x noise_stride] |noise params| of the base point
-    const int32_t *d_row = nullptr;       // [B]  row of model0 holding the base model of evaluation b
-    const double *model0 = nullptr;       // [rows x Nx] base model rows
+    const int32_t *d_row = nullptr;       // [B]  row of model0 holding the base point of evaluation b
+    // base point of the finite differences, two planes of [rows x Nx], fd_plane doubles apart: 1/M0 and y/M0.  Written by the base launch
+    // (WRITE_MODEL with fd_rows set, instead of the model rows), read by the DELTA launch (model0).
+    const double *model0 = nullptr;
+    double *fd_rows = nullptr;
+    size_t fd_plane = 0;
 };
 
 // Tile to dispatch first: three tiles below the lowest multiplet centre of a representative table (so the near-field tiles lead

@@ -505,7 +505,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     KSTAMP(4);
     // the power values: issued before the polynomial evaluation, consumed after it
 #pragma unroll
-    for (int k = 0; k < K; k++) yv[k] = a.y[min(bin[k], a.Nx - 1)];
+    for (int k = 0; k < K; k++) yv[k] = DELTA ? 0.0 : a.y[min(bin[k], a.Nx - 1)];  // (DELTA: y enters through the base point's y/M0 plane)
     if (FAST) __syncthreads();  // s_lt / s_coef visible (also when the evaluation has no multiplet chunk)
     if (FARFIELD) {
         if (s_anyfar && !PROBE_SKIP(4)) {  // workgroup-uniform: far multiplets and/or the background series
@@ -566,14 +566,23 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
                 Mv = Mv + (DELTA ? (white - nzo[nn - 1]) : white);
             }
             if (DELTA) {
-                // Mv = dM.  y/(M0+dM) - y/M0 = -y dM /(M0 (M0+dM));  ln(M0+dM) - ln M0 = log1p(dM/M0)
-                if (valid) {
-                    const double M0 = a.model0[(size_t)a.d_row[b] * a.Nx + bin[k]];
-                    const double r0 = rcp_nr2(M0), rn = rcp_nr2(M0 + Mv);
-                    s[0] = fma(-yv[k] * Mv, r0 * rn, s[0]);
-                    const double dl = Mv * r0;
-                    s[1] = s[1] + ((fabs(dl) < 1e-4) ? dl * fma(dl, fma(dl, 1.0 / 3.0, -0.5), 1.0) : log1p(dl));
-                }
+                // Mv = dM; u = dM / M0.  Change of the bin's likelihood term y/M + ln M:
+                //   y/(M0+dM) - y/M0 + ln(1 + dM/M0) = -(y/M0) u/(1+u) + log1p(u) = sum_n (-1)^n (y/M0 - 1/n) u^n.
+                // The base launch left 1/M0 and y/M0 per bin (two planes); a forward-difference step gives |u| ~ 1e-7 .. 1e-3, where five terms
+                // of the series are exact to rounding (omitted: u^6, < 1e-10 of the leading term for |u| <= 0.01) and cost a third of two
+                // reciprocals and a log1p; a bin beyond that (a step of percent size) takes the closed form -- wave-uniform choice.
+                const size_t o = (size_t)a.d_row[b] * a.Nx + (size_t)min(bin[k], a.Nx - 1);
+                const double r0 = a.model0[o], yr = a.model0[a.fd_plane + o];
+                const double u = Mv * r0;
+                double f;
+                if (!__any(valid && !(fabs(u) <= 0.01))) {
+                    double pz = fma(u, 0.2 - yr, yr - 0.25);
+                    pz = fma(u, pz, (1.0 / 3.0) - yr);
+                    pz = fma(u, pz, yr - 0.5);
+                    pz = fma(u, pz, 1.0 - yr);
+                    f = u * pz;
+                } else f = fma(-yr * u, rcp_nr2(1.0 + u), log1p(u));
+                if (valid) s[0] = s[0] + f;
             } else if (valid) {
                 if (PROBE_SKIP(8)) s[0] = s[0] + yv[k] * Mv;
                 else {
@@ -584,7 +593,13 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
         }
         Mk[k] = Mv;
         if (WRITE_MODEL) {
-            if (valid) a.model[(size_t)b * a.Nx + bin[k]] = Mv;
+            if (valid) {
+                if (a.fd_rows) {  // base point of a finite-difference batch: what the DELTA launch needs of it (see there)
+                    const double r0 = FAST ? rcp_nr2(Mv) : 1.0 / Mv;
+                    a.fd_rows[(size_t)b * a.Nx + bin[k]] = r0;
+                    a.fd_rows[a.fd_plane + (size_t)b * a.Nx + bin[k]] = yv[k] * r0;
+                } else a.model[(size_t)b * a.Nx + bin[k]] = Mv;
+            }
         }
     }
     if (FAST && !DELTA) {

@@ -26,6 +26,8 @@ EXTRA_ABI += [
     ("tamcmc_sampler_nvars", C.c_int64, [_vp]),
     ("tamcmc_sampler_get_info", C.c_int, [_vp, _i64p, C.c_int32]),
     ("tamcmc_sampler_get_move_counts", C.c_int, [_vp, _i64p]),
+    ("tamcmc_sampler_get_gradient", C.c_int, [_vp, _dp, _dp, _ip]),
+    ("tamcmc_sampler_get_last_test", C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     ("tamcmc_outputs_write_acceptance", C.c_int, [C.c_char_p, C.c_double, _dp, C.c_int32, C.c_int32]),
     ("tamcmc_outputs_read_acceptance", C.c_int, [C.c_char_p, _ip, C.c_int64, _i64p, _dp, _dp]),
     ("tamcmc_sampler_run", C.c_int, [_vp, C.c_int64, _dp, _dp]),
@@ -154,6 +156,25 @@ class Sampler:
             raise TamcmcError(rc, "tamcmc_sampler_get_info")
         keys = ("engine", "nvars", "nparams", "nchains", "adapt_in_lds", "fused_available", "chain_groups", "iter_fused", "iter_lockstep")
         return dict(zip(keys, (int(x) for x in v)))
+
+    def gradient(self):
+        """(grad, grad_prior [Nchains x Nvars], valid [Nchains]) the sampler holds for the chains' positions (use_drift = 1)."""
+        g, gp = np.zeros((self.nchains, self.nvars)), np.zeros((self.nchains, self.nvars))
+        v = np.zeros(self.nchains, dtype=np.int32)
+        rc = self._L.tamcmc_sampler_get_gradient(self._h, _p(g), _p(gp), _p(v, _ip))
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_get_gradient")
+        return g, gp, v
+
+    def last_test(self):
+        """Host engine: (proposals [Nchains x Nvars], their logL / logPrior / logPosterior [Nchains x 3], log q(x'|x) and log q(x|x') [Nchains x 2],
+        gradient at the proposals [Nchains x Nvars])."""
+        v, st, lq = np.zeros((self.nchains, self.nvars)), np.zeros((self.nchains, 3)), np.zeros((self.nchains, 2))
+        g = np.zeros((self.nchains, self.nvars))
+        rc = self._L.tamcmc_sampler_get_last_test(self._h, _p(v), _p(st), _p(lq), _p(g))
+        if rc != OK:
+            raise TamcmcError(rc, "tamcmc_sampler_get_last_test")
+        return v, st, lq, g
 
     def move_counts(self):
         """Per chain: iterations since creation whose record carries moved = 1 (tamcmc_sampler_get_move_counts)."""

@@ -153,7 +153,7 @@ def load(fast=False):
     lib.orc_langevin_drift.argtypes = [c_dp, C.c_double, C.c_double, C.c_double, c_dp, C.c_long, c_dp]
     lib.orc_langevin_iteration.restype = C.c_int
     lib.orc_langevin_iteration.argtypes = [C.POINTER(SamplerStar), C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_dp, c_dp, C.c_double,
-                                           C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_ip]
+                                           C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp, c_ip, c_dp]
     return lib
 
 
@@ -232,11 +232,12 @@ class Oracle:
 
     def sampler_iteration(self, star, y, Tcoefs, init_logL, state, law, i, z, u_mh, learn=False, do_swap=False, ind_A=0, u_swap=1.0,
                           literal_444=False, p=1.0, epsilon1=1e-12, epsilon2=1e-12, A1=1e14, target_acceptance=0.234, c0=10.0,
-                          use_drift=False, fd_step_rel=1e-7, delta=0.0, chain_mask=None):
+                          use_drift=False, fd_step_rel=1e-7, delta=0.0, chain_mask=None, prop_given=None):
         """One pass of MALA::execute's loop body.  state = dict(params, vars, logL, logPrior, logPost) [copied], law = (mu, cov, sigma)
         [copied].  Returns (new state incl. moved / Pmove / swapped / prop_vars / prop_stats, new law, rc).
         use_drift: the Langevin step (orc_langevin_iteration); the state then also carries diag [Nchains x 4] = log q(x'|x), log q(x|x'),
-        |drift(x)|, |drift(x')|; chain_mask [Nchains]: advance the flagged chains only."""
+        |drift(x)|, |drift(x')|; chain_mask [Nchains]: advance the flagged chains only; prop_given [Nchains x Nvars]: test at these
+        proposals (prop_vars still returns the oracle's own)."""
         f = lambda a: np.ascontiguousarray(np.array(a, dtype=np.float64, copy=True))
         st = {k: f(state[k]) for k in ("params", "vars", "logL", "logPrior", "logPost")}
         mu, cov, sigma = f(law[0]), f(law[1]), f(law[2])
@@ -251,7 +252,8 @@ class Oracle:
                                                  _dp(u), float(fd_step_rel), float(delta), _dp(st["params"]), _dp(st["vars"]), _dp(st["logL"]),
                                                  _dp(st["logPrior"]), _dp(st["logPost"]), _ip(moved), _dp(Pmove), _dp(mu), _dp(cov), _dp(sigma),
                                                  _ip(swapped), _dp(pv), _dp(ps), _dp(diag),
-                                                 _ip(np.ascontiguousarray(chain_mask, dtype=np.int32)) if chain_mask is not None else None)
+                                                 _ip(np.ascontiguousarray(chain_mask, dtype=np.int32)) if chain_mask is not None else None,
+                                                 _dp(f(prop_given)) if prop_given is not None else None)
             st["diag"] = diag
         else:
             rc = self.lib.orc_sampler_iteration(C.byref(S), int(i), int(learn), int(do_swap), int(ind_A), float(u_swap), int(literal_444), _dp(z), _dp(u),
