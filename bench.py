@@ -365,15 +365,15 @@ def main():
         agg = value / world * a.chains * 16.0 * a.nx / 1e9   # the whole timed region
         launches_per_iter = k_launches / max(a.steps, 1)
         fused = (a.engine == "device" and a.sampler == "mh" and a.step_scheme != 1 and prec == pkg.PRECISION_FAST)
-        pmc = committed_json("r02_pmc_traffic.json") or {}
-        pmc_sq = committed_json("r02_pmc_sq.json") or {}
+        pmc = committed_json("r03_pmc_traffic.json") or committed_json("r02_pmc_traffic.json") or {}
+        pmc_sq = committed_json("r03_pmc_sq.json") or committed_json("r02_pmc_sq.json") or {}
         valu = None
         if pmc_sq.get("SQ_INSTS_VALU_per_launch"):
             # wave-level VALU instructions x 64 lanes / duration: an upper bound of the fp64 lane-operation rate (integer/address VALU included)
             rate = pmc_sq["SQ_INSTS_VALU_per_launch"] * 64.0 * launches_per_iter / (elapsed / a.steps)
             valu = {"valu_lane_ops_per_s": rate, "frac_of_fp64_fma_peak": rate / FP64_FMA_PEAK, "peak_fma_per_s": FP64_FMA_PEAK,
                     "SQ_INSTS_VALU_per_launch": pmc_sq["SQ_INSTS_VALU_per_launch"], "launches_in_flight": round(launches_per_iter),
-                    "source": "profiles/r02_pmc_sq.json (rocprofv3 --pmc, separate pass): VALU instructions of one launch x 64 lanes x launches per iteration / iteration time"}
+                    "source": "profiles/r0N_pmc_sq.json of the newest round (rocprofv3 --pmc, separate pass): VALU instructions of one launch x 64 lanes x launches per iteration / iteration time"}
         out = {
             "metric": "MCMC samples/sec (whole node), 1e5 nu-bins x 100 params x 20 tempered chains",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -2,7 +2,7 @@
 """Turns gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries under profiles/:
 <tag>_kernel_stats.csv, <tag>_rocprof_summary.md, <tag>_pmc_traffic.json, <tag>_pmc_sq.json."""
 import csv, glob, json, os, shutil, sys, collections
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = f"gpurun_out/prof_{tag}"
 KERNEL = "k_step<1, 8>"          # the dominant kernel of the headline run: fused step, FAST arithmetic, 8 bins per lane
 os.makedirs("profiles", exist_ok=True)
