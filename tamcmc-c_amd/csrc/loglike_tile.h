@@ -525,7 +525,9 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     // ---- background + likelihood terms ----
     double s[2] = {0.0, 0.0};
     const double white = nz[nn - 1];
-    double prod = 1.0;  // FAST: sum_k ln M_k = ln prod_k M_k (one log per K bins)
+    // FAST: the thread's K bins share ONE logarithm and ONE reciprocal: sum_k ln M_k = ln prod_k M_k and sum_k y_k/M_k = N / prod_k M_k with
+    // N <- N M_k + y_k D built beside the product (three instructions per bin instead of a reciprocal with two Newton steps)
+    double prod = 1.0, ynum = 0.0;
     double Mk[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -586,7 +588,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
             } else if (valid) {
                 if (PROBE_SKIP(8)) s[0] = s[0] + yv[k] * Mv;
                 else {
-                    s[0] = fma(yv[k], rcp_nr2(Mv), s[0]);
+                    ynum = fma(ynum, Mv, yv[k] * prod);
                     prod = prod * Mv;
                 }
             }
@@ -603,11 +605,16 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
         }
     }
     if (FAST && !DELTA) {
-        if (prod > 1e-280 && prod < 1e280) s[1] = log(prod);
-        else {  // product out of range (or NaN): the plain sum of logs
+        if (prod > 1e-280 && prod < 1e280) {
+            s[1] = log(prod);
+            s[0] = s[0] + ynum * rcp_nr2(prod);
+        } else {  // product out of range (or NaN): bin by bin
 #pragma unroll
             for (int k = 0; k < K; k++)
-                if (bin[k] < a.Nx) s[1] = s[1] + log(Mk[k]);
+                if (bin[k] < a.Nx) {
+                    s[1] = s[1] + log(Mk[k]);
+                    s[0] = fma(yv[k], rcp_nr2(Mk[k]), s[0]);
+                }
         }
     }
     __syncthreads();
