@@ -149,41 +149,9 @@ __device__ __forceinline__ void accept_result(const DevSamplerArgs &a, int j, lo
     __syncthreads();
 }
 
-// Data exchanged between workgroups of ONE launch (the tiles' partial sums, the swap pair's outcomes) goes through device-scope
-// accesses that bypass the per-XCD L2 (MI355X: eight L2s, not coherent with each other for ordinary loads/stores).  A full
-// __threadfence() per tile would write back and invalidate the XCD's whole L2 -- including the resident spectrum -- 4000 times per launch.
-// (global address space spelled out: the accesses must be global_load/global_store ... sc1, not flat_ -- MI355X_MICROARCH.md, cross-workgroup
-// hand-offs: sc1 stores, vmcnt(0), an agent-scope atomic add; the workgroup whose add came last reads with sc1 loads)
-typedef double __attribute__((address_space(1))) *gdp_t;
-typedef const double __attribute__((address_space(1))) *gcdp_t;
-__device__ __forceinline__ double coherent_load(const double *p) { return __hip_atomic_load((gcdp_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coherent_store(double *p, double v) { __hip_atomic_store((gdp_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// every earlier memory operation of this wave has completed (write-through stores have reached memory) before anything later issues
-__device__ __forceinline__ void drain_memory_ops() {
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __builtin_amdgcn_s_waitcnt(0);
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-}
-
-// (A): the same sum by ONE wave, in k_finalize's order: 256 strided per-thread sums (four per lane here), shuffle tree per 64, the
-// four in order.  Every lane returns the total.  (device-scope loads: the partials were written by other workgroups of this launch)
-__device__ __forceinline__ double wave_partial_sum(const double *base, int ntiles) {
-    const int lane = threadIdx.x & 63;
-    double s1[TB / 64], s2[TB / 64];
-#pragma unroll
-    for (int q = 0; q < TB / 64; q++) { s1[q] = 0; s2[q] = 0; }
-    for (int t0 = 0; t0 < ntiles; t0 += TB) {  // virtual thread q*64+lane of k_finalize adds tile t0 + q*64 + lane in this round
-        double v1[TB / 64], v2[TB / 64];
-#pragma unroll
-        for (int q = 0; q < TB / 64; q++) {  // the round's loads first: one memory round trip instead of four
-            const int t = t0 + q * 64 + lane;
-            v1[q] = t < ntiles ? coherent_load(base + 2 * t) : 0.0;
-            v2[q] = t < ntiles ? coherent_load(base + 2 * t + 1) : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < TB / 64; q++)
-            if (t0 + q * 64 + lane < ntiles) { s1[q] = s1[q] + v1[q]; s2[q] = s2[q] + v2[q]; }
-    }
+// Sum of a chain's per-tile partials by ONE wave in k_finalize's order (kernels.hip): 256 strided per-thread sums (four per lane here),
+// a shuffle tree per 64, the four in order.  Every lane returns the total.
+__device__ __forceinline__ double wave_sum_in_order(const double (&s1)[TB / 64], const double (&s2)[TB / 64]) {
     double t1 = 0, t2 = 0;
 #pragma unroll
     for (int q = 0; q < TB / 64; q++) {
@@ -197,6 +165,25 @@ __device__ __forceinline__ double wave_partial_sum(const double *base, int ntile
         else { t1 = t1 + a1; t2 = t2 + a2; }
     }
     return __shfl(t1 + t2, 0, 64);
+}
+__device__ __forceinline__ double wave_partial_sum(const double *base, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    double s1[TB / 64], s2[TB / 64];
+#pragma unroll
+    for (int q = 0; q < TB / 64; q++) { s1[q] = 0; s2[q] = 0; }
+    for (int t0 = 0; t0 < ntiles; t0 += TB) {  // virtual thread q*64+lane of k_finalize adds tile t0 + q*64 + lane in this round
+        double v1[TB / 64], v2[TB / 64];
+#pragma unroll
+        for (int q = 0; q < TB / 64; q++) {  // the round's loads first: one memory round trip instead of four
+            const int t = t0 + q * 64 + lane;
+            v1[q] = t < ntiles ? base[2 * t] : 0.0;
+            v2[q] = t < ntiles ? base[2 * t + 1] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < TB / 64; q++)
+            if (t0 + q * 64 + lane < ntiles) { s1[q] = s1[q] + v1[q]; s2[q] = s2[q] + v2[q]; }
+    }
+    return wave_sum_in_order(s1, s2);
 }
 
 // Robbins-Monro adaptation of chain m's proposal law (MALA.cpp:296-319) and Cholesky of (Sigma+eps2 I) sigma
@@ -777,33 +764,34 @@ __global__ void __launch_bounds__(TB) k_iterate(const DevSamplerArgs a, const lo
 struct FusedArgs {
     int NS;                // candidate slots per iteration: 2C + 8 (two blocks of four extra slots for a swap pair's cross candidates)
     int xsplit;            // first chain of the second chain group (C: none).  A chain's cross candidates after a swap live in extra block
-                           // (chain >= xsplit), a pair (A, A+1) uses pair counter (A >= xsplit): the two groups' launches run on
-                           // different streams, possibly several iterations apart, and must never write what the other one still reads
-    // candidates of the iteration with parity q: [2][NS]...
-    double *cand_vars, *cand_params, *cand_logPr;
-    int *cand_stP, *cand_stR;          // status of the prior role / the rows role
-    tamcmc_multiplet *mults;           // [2][NS][per]
-    int *pairs, *nh, *nn;              // [2][2 NS], [2][NS], [2][NS]
-    double *noise;                     // [2][NS][stride]
-    double *bg;                        // [2][NS][ntiles][8] or nullptr
-    int *slot;                         // [2][C]   table slot of chain m's proposal at the iteration of that parity
+                           // (chain >= xsplit): the two groups' launches run on different streams, possibly several iterations apart,
+                           // and must never write what the other one still reads
+    // candidates of iteration i live in candidate set i mod 3: [3][NS]...  (launch i reads the sets of iterations i-1 and i and writes
+    // the set of iteration i+1)
+    double *cand_vars, *cand_params;
+    double *cand_logPr;                // [3][NS][2] the two halves of the log-prior's additive terms (wave_log_prior_part), added in order
+    int *cand_rej;                     // [3][NS]    a hard constraint fails: the log-prior is -inf
+    int *cand_stP, *cand_stR;          // [3][NS][2], [3][NS] status of the two prior roles / the rows role
+    tamcmc_multiplet *mults;           // [3][NS][per]
+    int *pairs, *nh, *nn;              // [3][2 NS], [3][NS], [3][NS]
+    double *noise;                     // [3][NS][stride]
+    double *bg;                        // [3][NS][ntiles][8] or nullptr
+    // per chain, by the parity of the iteration: written by the launch of that iteration (commit_chain), read by the next one
+    int *slot;                         // [2][C]   table slot of chain m's proposal at that iteration
+    double *prop_logPr;                // [2][C]   that proposal's log-prior ...
+    int *prop_st;                      // [2][C]   ... and status (prior role's, else rows role's)
+    double *quick;                     // [2][C][QN] that iteration's MH and swap tests as thresholds on the sums of the partials (quick_decide)
+    double *part;                      // [2][C][ntiles][2] the tiles' partial sums of that iteration
     double *lz;                        // [2][C][Nv] L z of chain m for the iteration of that parity, computed one launch ahead
-    unsigned *ticket;                  // [2][C][TK] two levels: [0] counts the chain's tile GROUPS that are complete, [1 + g] the tiles
-                                       //          of group g = tile mod NG that have delivered their partial sums; one 128-byte line
-                                       //          each (device-scope atomics on one line serialise in the memory-side atomic unit)
-    unsigned *pair_ticket;             // [2][2]   (parity, extra block) chains of the swap pair that have done their MH test
-    double *acc;                       // [2][C][5] MH outcome of chain m (acc, r, logL, logPr, logPost), read by the partner that resolves the swap
 };
 
-constexpr int ST_L = 1, ST_BR = 2, ST_ENTRY = 4, ST_LZ = 8;
-constexpr int NG = 8;                  // tile groups per chain (ticket level 1)
-constexpr int TKS = 32;                // unsigned per ticket line
-constexpr int TK = (1 + NG) * TKS;     // unsigned per chain
+constexpr int QN = 8;  // doubles per quick record (quick_decide): S*, kind, -pl/T, logL held, [pair's first chain: log u_swap, TA/TB - 1, TB/TA - 1], slot
+constexpr int ST_L = 1, ST_BR = 2, ST_ENTRY = 4, ST_LZ = 8, ST_FIRST = 16, ST_COMMIT = 32;
 
-// The settle functions are real calls (register budget) and get the argument blocks as pointers to their device-memory image.  That image
-// is written by the host only, and the pointer is the same in every lane: read through a wave-uniform pointer into constant memory, a
-// field costs a scalar load (SGPR, scalar cache) instead of a flat vector load per lane, and the pointers found there are known to be
-// global (global_load / global_store instead of flat_).
+// The decide / commit functions are real calls (register budget of the tile path) and get the argument blocks as pointers to their
+// device-memory image.  That image is written by the host only, and the pointer is the same in every lane: read through a wave-uniform
+// pointer into constant memory, a field costs a scalar load (SGPR, scalar cache) instead of a flat vector load per lane, and the
+// pointers found there are known to be global (global_load / global_store instead of flat_).
 typedef DevSamplerArgs __attribute__((address_space(4))) ConstArgs;
 typedef FusedArgs __attribute__((address_space(4))) ConstFused;
 __device__ __forceinline__ const void __attribute__((address_space(4))) *uniform_ptr(const void *p) {
@@ -812,191 +800,301 @@ __device__ __forceinline__ const void __attribute__((address_space(4))) *uniform
     return (const void __attribute__((address_space(4))) *)(((unsigned long long)hi << 32) | lo);
 }
 
-// The scalar part of a chain's settled state (ONE lane): what it holds, the slot of its next proposal, the record of its statistics.
-template <class AT, class FT>
-__device__ __forceinline__ void fused_scalars(const AT &a, const FT &f, int m, int src_acc, double src_r, const AcceptOut &o,
-                                              int next_slot, long it, int q, long rec) {
-    const int C = a.C, q1 = q ^ 1;
-    a.logL_cur[q1 * C + m] = o.logL;
-    a.logPr_cur[q1 * C + m] = o.logPr;
-    a.logPost_cur[q1 * C + m] = o.logPost;
-    f.slot[q1 * C + m] = next_slot;
-    a.moved[m] = src_acc;     // a swap exchanges the pair's moved / Pmove entries too (MALA.cpp:425-446)
-    a.Pmove[m] = src_r;
-    if (m == 0 && src_acc) a.counters[1] += 1;
-    a.counters[8 + m] += src_acc;
-    if (m == 0) a.counters[0] = it + 1;
-    if (a.stats && rec >= 0) {  // update_buffer_stat_criteria (MALA.cpp:708)
-        double *r = a.stats + ((size_t)rec * C + m) * 3;
-        r[0] = o.logL; r[1] = o.logPr; r[2] = o.logPost;
-    }
-}
+// What chain m enters iteration `it` with -- the outcome of iteration it-1's MH test and swap (MALA.cpp:397-461, 490-551).
+struct Decided {
+    int slot;       // candidate slot (set it mod 3) of the chain's proposal at iteration `it`
+    int src;        // chain whose post-test position the chain continues from: itself, or its swap partner
+    int src_acc;    // 1: that position is src's proposal of iteration it-1 (candidate set (it-1) mod 3, slot src_ps); 0: what src held
+    int src_par;    // parity of the state arrays that hold src's position (src_acc == 0) -- the previous iteration's, or, in the first
+                    // launch of a stretch, this iteration's (the chains are settled)
+    int src_ps;
+    int swap_first; // first chain of iteration it-1's swap pair when chain m is in it, else -1
+    int swapped;
+    double r;       // move probability of src's test (a swap exchanges the pair's moved / Pmove entries too, MALA.cpp:425-446)
+    AcceptOut o;    // the scalars the chain holds (re-tempered after a swap)
+};
 
-// Writes chain m's settled state for the next iteration: position = chain `src`'s post-test position (its own, or the swap partner's),
-// scalars from `o` (already re-tempered after a swap); records the sample; names the slot of chain m's next proposal.
-template <class AT, class FT>
-__device__ __forceinline__ void fused_finalize(const AT &a, const FT &f, int m, int src, int src_acc, double src_r,
-                                               const AcceptOut &o, int next_slot, long it, int q, long rec) {
-    const int lane = threadIdx.x, C = a.C, Nv = a.Nv, Np = a.desc.Np, q1 = q ^ 1;
-    const double *sv, *sp;
-    if (src_acc) {
-        const int ps = f.slot[q * C + src] & 0xffff;
-        sv = f.cand_vars + ((size_t)q * f.NS + ps) * Nv;
-        sp = f.cand_params + ((size_t)q * f.NS + ps) * Np;
-    } else {
-        sv = a.vars_cur + ((size_t)q * C + src) * Nv;
-        sp = a.params_cur + ((size_t)q * C + src) * Np;
-    }
-    double *dv = a.vars_cur + ((size_t)q1 * C + m) * Nv, *dp = a.params_cur + ((size_t)q1 * C + m) * Np;
-    double *rv = (a.samples && rec >= 0) ? a.samples + ((size_t)rec * C + m) * Nv : nullptr;  // update_buffer_params (MALA.cpp:710)
-    for (int i = lane; i < Nv; i += 64) { const double v = sv[i]; dv[i] = v; if (rv) rv[i] = v; }
-    for (int i = lane; i < Np; i += 64) dp[i] = sp[i];
-    if (lane == 0) fused_scalars(a, f, m, src_acc, src_r, o, next_slot, it, q, rec);
-}
-
-// Chain m of the swap pair (A, A+1) has done its MH test (outcome in the arguments): publish it; the second of the two to get here
-// resolves the swap (MALA.cpp:397-461) and writes both chains' settled states.
-__device__ __attribute__((noinline)) void fused_settle_pair(const DevSamplerArgs *ga, const FusedArgs *gf, int m, int A, double u, int o_acc, double o_r,
-                                                            double o_logL, double o_logPr, double o_logPost, long it, int q, long rec) {
+// Iteration it-1 of chain m decided by ONE wave from what launch it-1 left in memory: the tiles' partial sums (summed in k_finalize's
+// order), the proposal's prior and status, the scalars the chain held.  Every workgroup of launch `it` that needs the outcome -- each
+// likelihood tile of the chain (its table slot), the chain's commit workgroup, the candidate roles built on the chain's vectors --
+// recomputes it from the same inputs: same result everywhere, no hand-off inside a launch (no tickets, no device-scope accesses), and no
+// settle step at the end of the launch's critical path.  For the two chains of iteration it-1's swap pair both tests are evaluated
+// (lanes 0 and 1) and the swap resolved.  Returns the slot; `out` (LDS, may be null) gets the rest, written by lane 0.
+__device__ __attribute__((noinline)) int decide(const DevSamplerArgs *ga, const FusedArgs *gf, int m, long it, int q, int settled, Decided *out) {
     const ConstArgs &a = *(const ConstArgs *)uniform_ptr(ga);
     const ConstFused &f = *(const ConstFused *)uniform_ptr(gf);
-    const int lane = threadIdx.x, C = a.C;
-    AcceptOut o;
-    o.acc = o_acc; o.r = o_r; o.logL = o_logL; o.logPr = o_logPr; o.logPost = o_logPost;
-    if (lane == 0) {
-        double *w = f.acc + ((size_t)q * C + m) * 5;
-        coherent_store(w, (double)o.acc); coherent_store(w + 1, o.r); coherent_store(w + 2, o.logL); coherent_store(w + 3, o.logPr);
-        coherent_store(w + 4, o.logPost);
+    const int lane = threadIdx.x & 63, C = a.C;
+    if (settled) {  // first launch of a stretch: nothing is pending, the chain's slot was named by the launch that settled it
+        const int s = f.slot[q * C + m] & 0xffff;
+        if (out && lane == 0) {
+            Decided d;
+            d.slot = s; d.src = m; d.src_acc = 0; d.src_par = q; d.src_ps = 0; d.swap_first = -1; d.swapped = 0; d.r = 0;
+            d.o.acc = 0; d.o.r = 0; d.o.logL = 0; d.o.logPr = 0; d.o.logPost = 0;
+            *out = d;
+        }
+        return s;
     }
-    drain_memory_ops();
-    unsigned first = 0;
-    const int xb = (A >= f.xsplit) ? 1 : 0;  // the pair's extra block
-    if (lane == 0) first = atomicAdd(&f.pair_ticket[2 * q + xb], 1u);
-    first = __shfl(first, 0, 64);
-    if (first == 0) return;  // the partner is still being evaluated: its last tile does the rest
-    const int partner = (m == A) ? A + 1 : A;
-    AcceptOut op = {0, 0., 0., 0., 0.};
-    if (lane == 0) {
-        const double *w = f.acc + ((size_t)q * C + partner) * 5;
-        op.acc = (int)coherent_load(w); op.r = coherent_load(w + 1); op.logL = coherent_load(w + 2); op.logPr = coherent_load(w + 3);
-        op.logPost = coherent_load(w + 4);
-    }
-    op.acc = __shfl(op.acc, 0, 64); op.r = __shfl(op.r, 0, 64);
-    op.logL = __shfl(op.logL, 0, 64); op.logPr = __shfl(op.logPr, 0, 64); op.logPost = __shfl(op.logPost, 0, 64);
-    AcceptOut oA = (m == A) ? o : op, oB = (m == A) ? op : o;
-    const int accA = oA.acc, accB = oB.acc;
-    const double rA = oA.r, rB = oB.r;
-    const int swapped = resolve_swap(a, A, u, oA, oB);
-    if (lane == 0) {
-        atomicAdd((unsigned long long *)&a.counters[2], 1ull);
-        if (swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
-    }
-    const int B = A + 1;
-    if (swapped) {  // each side continues from the other's post-test position: the extra candidate slots 2C .. 2C+3
-        fused_finalize(a, f, A, B, accB, rB, oA, 2 * C + (A >= f.xsplit ? 4 : 0) + accB, it, q, rec);
-        fused_finalize(a, f, B, A, accA, rA, oB, 2 * C + (B >= f.xsplit ? 4 : 0) + 2 + accA, it, q, rec);
+    const int p = q ^ 1, ntiles = a.ntiles;
+    const long itp = it - 1;
+    int A = -1;
+    double u = 0;
+    if (is_swap_iter(a, itp)) A = swap_first(a, itp, &u);
+    const bool in_pair = A >= 0 && (m == A || m == A + 1);
+    const int j0 = in_pair ? A : m;
+    const int jl = (in_pair && lane == 1) ? A + 1 : j0;  // lane 1 tests the pair's second chain, every other lane repeats lane 0
+    // every load before any arithmetic (one memory round trip): the scalars of this lane's chain, the partial sums of one or two chains
+    const int ps = f.slot[p * C + jl] & 0xffff, st = f.prop_st[p * C + jl];
+    const double pl = f.prop_logPr[p * C + jl], hL = a.logL_cur[p * C + jl], hP = a.logPr_cur[p * C + jl], hQ = a.logPost_cur[p * C + jl];
+    const double Tj = a.Tcoefs[jl], il = a.init_logL[jl];
+    const double *b0 = f.part + ((size_t)p * C + j0) * ntiles * 2;
+    double S0, S1 = 0;
+    if (ntiles <= TB) {  // the usual case, both chains' loads in flight together
+        double v1[TB / 64], v2[TB / 64], w1[TB / 64], w2[TB / 64];
+#pragma unroll
+        for (int k = 0; k < TB / 64; k++) {
+            const int t = k * 64 + lane;
+            const bool in = t < ntiles;
+            v1[k] = in ? b0[2 * t] : 0.0;
+            v2[k] = in ? b0[2 * t + 1] : 0.0;
+            w1[k] = (in && in_pair) ? b0[2 * (ntiles + t)] : 0.0;
+            w2[k] = (in && in_pair) ? b0[2 * (ntiles + t) + 1] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < TB / 64; k++) { v1[k] = 0.0 + v1[k]; v2[k] = 0.0 + v2[k]; w1[k] = 0.0 + w1[k]; w2[k] = 0.0 + w2[k]; }  // (wave_partial_sum's first round)
+        S0 = wave_sum_in_order(v1, v2);
+        if (in_pair) S1 = wave_sum_in_order(w1, w2);
     } else {
-        fused_finalize(a, f, A, A, accA, rA, oA, 2 * A + accA, it, q, rec);
-        fused_finalize(a, f, B, B, accB, rB, oB, 2 * B + accB, it, q, rec);
+        S0 = wave_partial_sum(b0, ntiles);
+        if (in_pair) S1 = wave_partial_sum(b0 + (size_t)ntiles * 2, ntiles);
     }
+    AcceptOut o = mh_outcome(a, jl, itp, (in_pair && lane == 1) ? S1 : S0, pl, st, hL, hP, hQ, Tj, il);
+    AcceptOut o0, o1;
+    o0.acc = __shfl(o.acc, 0, 64); o0.r = __shfl(o.r, 0, 64); o0.logL = __shfl(o.logL, 0, 64); o0.logPr = __shfl(o.logPr, 0, 64);
+    o0.logPost = __shfl(o.logPost, 0, 64);
+    const int ps0 = __shfl(ps, 0, 64);
+    Decided d;
+    d.swap_first = -1; d.swapped = 0;
+    if (!in_pair) {
+        d.slot = 2 * m + o0.acc; d.src = m; d.src_acc = o0.acc; d.src_par = p; d.src_ps = ps0; d.r = o0.r; d.o = o0;
+    } else {
+        o1.acc = __shfl(o.acc, 1, 64); o1.r = __shfl(o.r, 1, 64); o1.logL = __shfl(o.logL, 1, 64); o1.logPr = __shfl(o.logPr, 1, 64);
+        o1.logPost = __shfl(o.logPost, 1, 64);
+        const int ps1 = __shfl(ps, 1, 64);
+        const int accA = o0.acc, accB = o1.acc;
+        const double rA = o0.r, rB = o1.r;
+        const int swapped = resolve_swap(a, A, u, o0, o1);  // (o0 = chain A's, o1 = chain B's: re-tempered in place)
+        d.swap_first = A; d.swapped = swapped; d.src_par = p;
+        const int B = A + 1;
+        if (swapped) {  // each side continues from the other's post-test position: the extra candidate slots 2C .. 2C+3 (+4: second block)
+            if (m == A) { d.slot = 2 * C + (A >= f.xsplit ? 4 : 0) + accB; d.src = B; d.src_acc = accB; d.src_ps = ps1; d.r = rB; d.o = o0; }
+            else { d.slot = 2 * C + (B >= f.xsplit ? 4 : 0) + 2 + accA; d.src = A; d.src_acc = accA; d.src_ps = ps0; d.r = rA; d.o = o1; }
+        } else {
+            if (m == A) { d.slot = 2 * A + accA; d.src = A; d.src_acc = accA; d.src_ps = ps0; d.r = rA; d.o = o0; }
+            else { d.slot = 2 * B + accB; d.src = B; d.src_acc = accB; d.src_ps = ps1; d.r = rB; d.o = o1; }
+        }
+    }
+    if (out && lane == 0) *out = d;
+    return d.slot;
 }
 
-// The chain's settle step, run by the wave of the chain's LAST tile (a real function call with pointer arguments, like the candidate
-// roles: inlined into the tile body it would raise the kernel's register allocation above three waves per SIMD).
-__device__ __attribute__((noinline)) void fused_settle(const DevSamplerArgs *ga, const FusedArgs *gf, int m, int ps, long it, int q, long rec) {
+// Chain m's workgroup of launch `it` (one wave): writes what iteration it-1 decided -- the chain's state for iteration `it` (parity q),
+// the record of iteration it-1 (update_buffer_params / update_buffer_stat_criteria, MALA.cpp:708-710), the move flags and counters -- and,
+// for the launch of iteration it+1, the slot, prior and status of the chain's proposal at iteration `it`.  With ST_COMMIT alone (after the
+// last iteration of a stretch) the launch holds nothing else.
+__device__ __attribute__((noinline)) void commit_chain(const DevSamplerArgs *ga, const FusedArgs *gf, int m, long it, int q, int settled, long rec,
+                                                       Decided *dec) {
+    const int slot = decide(ga, gf, m, it, q, settled, dec);
+    __syncthreads();
     const ConstArgs &a = *(const ConstArgs *)uniform_ptr(ga);
     const ConstFused &f = *(const ConstFused *)uniform_ptr(gf);
     const int lane = threadIdx.x, C = a.C, Nv = a.Nv, Np = a.desc.Np;
-    // Everything that does not depend on the sums is requested first (this wave is the launch's critical tail): the proposal's prior and
-    // status, what the chain holds, and BOTH vectors the chain may continue from (its position and its proposal).
-    // (ps = the slot of the chain's proposal: the tile that calls knows it, no load needed to find the proposal's data)
-    int stP = 0, stR = 0;
-    double c_logPr = 0, h_logL = 0, h_logPr = 0, h_logPost = 0, Tm = 1, il = 0;
+    const Decided d = *dec;
     if (lane == 0) {
-        stP = f.cand_stP[q * f.NS + ps]; stR = f.cand_stR[q * f.NS + ps]; c_logPr = f.cand_logPr[q * f.NS + ps];
-        h_logL = a.logL_cur[q * C + m]; h_logPr = a.logPr_cur[q * C + m]; h_logPost = a.logPost_cur[q * C + m];
-        Tm = a.Tcoefs[m]; il = a.init_logL[m];
+        const size_t gs = (size_t)(it % 3) * f.NS + slot;
+        const int stP0 = f.cand_stP[2 * gs], stP1 = f.cand_stP[2 * gs + 1], stR = f.cand_stR[gs];
+        const double lp = f.cand_rej[gs] ? -INFINITY : f.cand_logPr[2 * gs] + f.cand_logPr[2 * gs + 1];
+        const int stm = stP0 != TAMCMC_OK ? stP0 : (stP1 != TAMCMC_OK ? stP1 : stR);
+        f.prop_logPr[q * C + m] = lp;
+        f.prop_st[q * C + m] = stm;
+        // The test of iteration `it` (mh_outcome) as a threshold on S = sum of the tiles' partials, for the next launch's quick_decide:
+        // accept <=> log u <= -pl S / T + logPr - logPost_cur <=> S <= S*.  Everything but S is known here.
+        double *w = f.quick + ((size_t)q * C + m) * QN;
+        const double Tm = a.Tcoefs[m];
+        double Sstar = 0, ok = -1;  // (-1: no shortcut, decide() it)
+        double u, u1;
+        rng_uniform2(a.seed, RNG_ACCEPT, (uint32_t)m, (uint64_t)it, 0, u, u1);
+        if (stm == TAMCMC_OK && !(lp == -INFINITY || isnan(lp))) {
+            const double cur = settled ? a.logPost_cur[q * C + m] : d.o.logPost;
+            Sstar = -((log(u) - lp + cur) * Tm) / (double)a.pl;
+            if (isfinite(Sstar)) ok = 1;
+        } else if (u > 0.0) ok = 2;  // r = 0 whatever the sums (mh_outcome): rejected
+        w[0] = Sstar; w[1] = ok; w[2] = -(double)a.pl / Tm; w[3] = settled ? a.logL_cur[q * C + m] : d.o.logL;
+        double lus = 0, k1 = 0, k2 = 0;
+        if (is_swap_iter(a, it)) {  // the swap test of iteration `it`, left by the pair's first chain: u <= exp(LA TA/TB + LB TB/TA - LA - LB)
+            double us;
+            if (swap_first(a, it, &us) == m) {
+                const double TB = a.Tcoefs[m + 1];
+                lus = log(us); k1 = Tm / TB - 1.0; k2 = TB / Tm - 1.0;
+            }
+        }
+        w[4] = lus; w[5] = k1; w[6] = k2; w[7] = (double)slot;
     }
-    constexpr int ME = 2;  // vector elements per lane held in registers (longer vectors take the generic copy)
-    const bool in_regs = Nv <= 64 * ME && Np <= 64 * ME;
-    double r_pv[ME], r_cv[ME], r_pp[ME], r_cp[ME];
-    if (in_regs) {
-        const double *pv = f.cand_vars + ((size_t)q * f.NS + ps) * Nv, *pp = f.cand_params + ((size_t)q * f.NS + ps) * Np;
-        const double *cv = a.vars_cur + ((size_t)q * C + m) * Nv, *cp = a.params_cur + ((size_t)q * C + m) * Np;
-#pragma unroll
-        for (int e = 0; e < ME; e++) {
-            const int i = lane + 64 * e;
-            r_pv[e] = i < Nv ? pv[i] : 0.0; r_cv[e] = i < Nv ? cv[i] : 0.0;
-            r_pp[e] = i < Np ? pp[i] : 0.0; r_cp[e] = i < Np ? cp[i] : 0.0;
+    if (settled) return;
+    const double *sv, *sp;
+    if (d.src_acc) {
+        const size_t gp = (size_t)((it - 1) % 3) * f.NS + d.src_ps;
+        sv = f.cand_vars + gp * Nv;
+        sp = f.cand_params + gp * Np;
+    } else {
+        sv = a.vars_cur + ((size_t)d.src_par * C + d.src) * Nv;
+        sp = a.params_cur + ((size_t)d.src_par * C + d.src) * Np;
+    }
+    double *dv = a.vars_cur + ((size_t)q * C + m) * Nv, *dp = a.params_cur + ((size_t)q * C + m) * Np;
+    double *rv = (a.samples && rec >= 0) ? a.samples + ((size_t)rec * C + m) * Nv : nullptr;
+    for (int i = lane; i < Nv; i += 64) { const double v = sv[i]; dv[i] = v; if (rv) rv[i] = v; }
+    for (int i = lane; i < Np; i += 64) dp[i] = sp[i];
+    if (lane == 0) {
+        a.logL_cur[q * C + m] = d.o.logL;
+        a.logPr_cur[q * C + m] = d.o.logPr;
+        a.logPost_cur[q * C + m] = d.o.logPost;
+        f.slot[q * C + m] = slot;
+        a.moved[m] = d.src_acc;
+        a.Pmove[m] = d.r;
+        if (m == 0 && d.src_acc) a.counters[1] += 1;
+        a.counters[8 + m] += d.src_acc;
+        if (m == 0) a.counters[0] = it;
+        if (d.swap_first == m) {  // (the pair's first chain counts the swap step)
+            atomicAdd((unsigned long long *)&a.counters[2], 1ull);  // (the two chain groups' launches run side by side)
+            if (d.swapped) atomicAdd((unsigned long long *)&a.counters[3], 1ull);
+        }
+        if (a.stats && rec >= 0) {
+            double *r = a.stats + ((size_t)rec * C + m) * 3;
+            r[0] = d.o.logL; r[1] = d.o.logPr; r[2] = d.o.logPost;
         }
     }
-    // ---- the chain's MH test (MALA.cpp:490-551)
-    const double S = wave_partial_sum(a.partials + (size_t)m * a.ntiles * 2, a.ntiles);
-    AcceptOut o = {0, 0., 0., 0., 0.};
-    if (lane == 0) o = mh_outcome(a, m, it, S, c_logPr, stP != TAMCMC_OK ? stP : stR, h_logL, h_logPr, h_logPost, Tm, il);
-    o.acc = __shfl(o.acc, 0, 64); o.r = __shfl(o.r, 0, 64);
-    o.logL = __shfl(o.logL, 0, 64); o.logPr = __shfl(o.logPr, 0, 64); o.logPost = __shfl(o.logPost, 0, 64);
-    // ---- parallel tempering (MALA.cpp:397-461): the second chain of the pair to get here resolves the swap for both
-    int A = -1;
-    double u = 0;
-    if (is_swap_iter(a, it)) A = swap_first(a, it, &u);
-    if (A < 0 || (m != A && m != A + 1)) {  // not in the swap pair (or no swap step at this iteration)
-        if (!in_regs) { fused_finalize(a, f, m, m, o.acc, o.r, o, 2 * m + o.acc, it, q, rec); return; }
-        // the chain keeps its own position or takes its own proposal: both are in registers
-        const int q1 = q ^ 1;
-        double *dv = a.vars_cur + ((size_t)q1 * C + m) * Nv, *dp = a.params_cur + ((size_t)q1 * C + m) * Np;
-        double *rv = (a.samples && rec >= 0) ? a.samples + ((size_t)rec * C + m) * Nv : nullptr;  // update_buffer_params (MALA.cpp:710)
-#pragma unroll
-        for (int e = 0; e < ME; e++) {
-            const int i = lane + 64 * e;
-            if (i < Nv) { const double v = o.acc ? r_pv[e] : r_cv[e]; dv[i] = v; if (rv) rv[i] = v; }
-            if (i < Np) dp[i] = o.acc ? r_pp[e] : r_cp[e];
-        }
-        if (lane == 0) fused_scalars(a, f, m, o.acc, o.r, o, 2 * m + o.acc, it, q, rec);
-        return;
-    }
-    fused_settle_pair(ga, gf, m, A, u, o.acc, o.r, o.logL, o.logPr, o.logPost, it, q, rec);
 }
 
-// Tail of the likelihood tiles of the fused step: every tile's wave calls it once its partial sums are written.
-struct SettleTail {
-    const DevSamplerArgs &a;
-    const FusedArgs &f;
+// decide() for the workgroups that only need to know WHERE chain m stands -- the likelihood tiles (its table slot), the candidate roles
+// (slot and the vector the chain continues from) -- the cheapest way that is still certain.  The MH test of iteration it-1 is a
+// comparison of S = the sum of launch it-1's partials with a threshold S* that the previous launch's commit workgroup has left
+// (commit_chain: everything in the test but S is known one launch earlier).  S is summed here in any order; when it is further from S*
+// than every rounding involved could explain (summation: n eps sum|v| ~ 2e-14 sum|v|; the threshold and the test's own exp / division:
+// a few eps of |S*|; the margin is 1e-11 of those magnitudes) the outcome is the exact test's.  The swap test of iteration it-1's pair
+// (pairA, named by the host: the same Philox draw) is taken the same way: log u against LA (TA/TB - 1) + LB (TB/TA - 1) with the
+// post-test likelihoods from the approximate sums.  Otherwise -- about once in 1e5 tests -- decide() evaluates everything as written.
+// A decide() of ~2000 dependent instructions costs a lone wave 5 us at the head of the launch's longest chains; this one ~0.5 us.
+// (the shortcut itself, a leaf function: -1 = undecided)
+__device__ __attribute__((noinline)) int quick_decide_leaf(const DevSamplerArgs *ga, const FusedArgs *gf, int m, int q, int pairA, Decided *out) {
+    const ConstArgs &a = *(const ConstArgs *)uniform_ptr(ga);
+    const ConstFused &f = *(const ConstFused *)uniform_ptr(gf);
+    const int lane = threadIdx.x & 63, C = a.C;
+    const int p = q ^ 1, n2 = 2 * a.ntiles;
+    const bool in_pair = pairA >= 0 && (m == pairA || m == pairA + 1);
+    const int j0 = in_pair ? pairA : m;
+    const double *b0 = f.part + ((size_t)p * C + j0) * n2;
+    const double *r0 = f.quick + ((size_t)p * C + j0) * QN;
+    // every load first: the records (lane k < QN: field k of chain j0, lane QN + k: of chain j0 + 1), the partial sums
+    const double rec = (lane < (in_pair ? 2 * QN : QN)) ? r0[lane] : 0.0;
+    double s0 = 0, a0 = 0, s1 = 0, a1 = 0;
+    for (int t0 = 0; t0 < n2; t0 += 512) {
+        double v[8], w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int t = t0 + k * 64 + lane;
+            v[k] = t < n2 ? b0[t] : 0.0;
+            w[k] = (in_pair && t < n2) ? b0[n2 + t] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s0 += v[k]; a0 += fabs(v[k]); s1 += w[k]; a1 += fabs(w[k]); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_xor(s0, off, 64); a0 += __shfl_xor(a0, off, 64); }
+    if (in_pair) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); a1 += __shfl_xor(a1, off, 64); }
+    }
+    const double St0 = __shfl(rec, 0, 64), ok0 = __shfl(rec, 1, 64);
+    const int ps0 = (int)__shfl(rec, 7, 64);
+    // kind 1: threshold test; kind 2: the proposal cannot be accepted (outside a prior's support, or its table failed: r = 0 and u > 0) --
+    // its partial sums may be anything (an empty slot's tiles are skipped)
+    int acc0 = 0;
+    if (ok0 == 2.0) { s0 = 0; a0 = 0; }
+    else if (ok0 > 0 && fabs(s0 - St0) > 1e-11 * (a0 + fabs(St0))) acc0 = s0 < St0 ? 1 : 0;  // (a NaN sum fails the comparison)
+    else return -1;
+    Decided d;
+    d.swap_first = -1; d.swapped = 0; d.src_par = p; d.r = 0;
+    d.o.acc = 0; d.o.r = 0; d.o.logL = 0; d.o.logPr = 0; d.o.logPost = 0;  // (the scalars are the commit workgroup's business: decide())
+    if (!in_pair) { d.slot = 2 * m + acc0; d.src = m; d.src_acc = acc0; d.src_ps = ps0; }
+    else {
+        const double St1 = __shfl(rec, QN, 64), ok1 = __shfl(rec, QN + 1, 64);
+        const int ps1 = (int)__shfl(rec, QN + 7, 64);
+        int acc1 = 0;
+        if (ok1 == 2.0) { s1 = 0; a1 = 0; }
+        else if (ok1 > 0 && fabs(s1 - St1) > 1e-11 * (a1 + fabs(St1))) acc1 = s1 < St1 ? 1 : 0;
+        else return -1;
+        const double c0 = __shfl(rec, 2, 64), c1 = __shfl(rec, QN + 2, 64);
+        const double LA = acc0 ? c0 * s0 : __shfl(rec, 3, 64), LB = acc1 ? c1 * s1 : __shfl(rec, QN + 3, 64);
+        const double lus = __shfl(rec, 4, 64), x = LA * __shfl(rec, 5, 64) + LB * __shfl(rec, 6, 64);
+        if (!(fabs(x - lus) > 1e-11 * (fabs(c0) * a0 + fabs(c1) * a1 + fabs(LA) + fabs(LB)))) return -1;
+        const int swapped = x > lus ? 1 : 0;
+        const int A = pairA, B = pairA + 1;
+        d.swap_first = A; d.swapped = swapped;
+        if (swapped) {
+            if (m == A) { d.slot = 2 * C + (A >= f.xsplit ? 4 : 0) + acc1; d.src = B; d.src_acc = acc1; d.src_ps = ps1; }
+            else { d.slot = 2 * C + (B >= f.xsplit ? 4 : 0) + 2 + acc0; d.src = A; d.src_acc = acc0; d.src_ps = ps0; }
+        } else {
+            if (m == A) { d.slot = 2 * A + acc0; d.src = A; d.src_acc = acc0; d.src_ps = ps0; }
+            else { d.slot = 2 * B + acc1; d.src = B; d.src_acc = acc1; d.src_ps = ps1; }
+        }
+    }
+    if (out && lane == 0) *out = d;
+    return d.slot;
+}
+
+__device__ __forceinline__ int quick_decide(const DevSamplerArgs *ga, const FusedArgs *gf, int m, long it, int q, int settled, int pairA,
+                                            Decided *out) {
+    if (settled) return decide(ga, gf, m, it, q, 1, out);
+    const int s = quick_decide_leaf(ga, gf, m, q, pairA, out);
+    return s >= 0 ? s : decide(ga, gf, m, it, q, 0, out);
+}
+
+// Hook of the likelihood tiles of the fused step: evaluation b = chain first + b.
+struct StepTiles {
     const DevSamplerArgs *ga;
     const FusedArgs *gf;
-    long it, rec;
-    int q, first;  // first: chain of the launch's evaluation 0 (a launch covers the chains of one group, or all of them)
-    static constexpr bool coherent_partials = true;
-    __device__ __forceinline__ void operator()(int b, int tile, int ps) const {
-        const int lane = threadIdx.x, C = a.C, m = first + b;
-        drain_memory_ops();  // this tile's two partial sums (write-through stores) are in memory before the ticket counts the tile
-        unsigned *tk = f.ticket + ((size_t)q * C + m) * TK;
-        const int g = tile % NG, in_group = (a.ntiles - g + NG - 1) / NG;  // tiles g, g+NG, ... < ntiles
-        unsigned old = 0;
-        if (lane == 0) {
-            old = atomicAdd(&tk[(1 + g) * TKS], 1u);
-            if (old == (unsigned)(in_group - 1)) old = atomicAdd(&tk[0], 1u) + 0x10000u;  // the group's last tile reports the group
-        }
-        old = __shfl(old, 0, 64);
-        const int ngroups = a.ntiles < NG ? a.ntiles : NG;
-        if (old != 0x10000u + (unsigned)(ngroups - 1)) return;  // not the chain's last tile (wave-uniform)
-        fused_settle(ga, gf, m, ps, it, q, rec);
-    }
+    long it;
+    int q, first, settled, pairA;
+    static constexpr bool coherent_partials = false;
+    __device__ __forceinline__ int slot(const LoglikeArgs &, int b) const { return quick_decide(ga, gf, first + b, it, q, settled, pairA, nullptr); }
+    __device__ __forceinline__ void operator()(int, int, int) const {}
 };
 
 // The three kinds of work on one candidate (see candidate_role); the proposal vector is in LDS.
 // (They are real function calls -- see candidate_role -- so their arguments are pointers to the DEVICE-MEMORY copies of the argument
 // blocks: a reference to a kernel argument would have to be copied to the scratch stack first.)
-__device__ __attribute__((noinline)) void role_prior(const DevSamplerArgs *ga, const FusedArgs *gf, size_t gs, const double *s_vars,
+__device__ __attribute__((noinline)) void role_prior(const DevSamplerArgs *ga, const FusedArgs *gf, size_t gs, int h, const double *s_vars,
                                                      const double *s_params, const UnpackLds *Up) {
     const DevSamplerArgs &a = *ga;
     const FusedArgs &f = *gf;
     const UnpackLds U = *Up;
     const int Nv = a.Nv, Np = a.desc.Np, tid = threadIdx.x;
-    for (int i = tid; i < Nv; i += 64) f.cand_vars[gs * Nv + i] = s_vars[i];
-    for (int i = tid; i < Np; i += 64) f.cand_params[gs * Np + i] = s_params[i];
-    const double logPr = wave_log_prior(a.desc, s_params, U, TB - 128);  // the proposal kernel's 128 term lanes (dev_unpack.h)
-    if (tid == 0) { f.cand_logPr[gs] = logPr; f.cand_stP[gs] = *U.status; }
+    if (h == 0) {
+        for (int i = tid; i < Nv; i += 64) f.cand_vars[gs * Nv + i] = s_vars[i];
+        for (int i = tid; i < Np; i += 64) f.cand_params[gs * Np + i] = s_params[i];
+    }
+    int rej = 0;
+#ifdef TAMCMC_PROBE
+    long ps_[4] = {0, 0, 0, 0};
+    const double fh = wave_log_prior_part(a.desc, s_params, U, TB - 128, h, &rej, ps_);
+    if (tid == 0 && (int)(gs % f.NS) == 2) { long *w = a.counters + 8 + a.C + 16 * h + 4; w[0] += ps_[1] - ps_[0]; w[1] += ps_[2] - ps_[1]; }
+#else
+    const double fh = wave_log_prior_part(a.desc, s_params, U, TB - 128, h, &rej);  // the proposal kernel's 128 term lanes (dev_unpack.h)
+#endif
+    if (tid == 0) {
+        f.cand_logPr[2 * gs + h] = fh;
+        f.cand_stP[2 * gs + h] = *U.status;
+        if (h == 0) f.cand_rej[gs] = rej;
+    }
 }
 __device__ __forceinline__ TablePtrs candidate_tables(const DevSamplerArgs &a, const FusedArgs &f, int q_dst) {
     TablePtrs T;
@@ -1015,7 +1113,17 @@ __device__ __attribute__((noinline)) void role_rows(const DevSamplerArgs *ga, co
     const TablePtrs T = candidate_tables(a, f, q_dst);
     // the table is built whatever the prior says (this role does not know it): a vector outside a prior's support is rejected by
     // the settle step before its likelihood is looked at (model_def.cpp:476-480), a table that cannot be built leaves an empty slot
+#ifdef TAMCMC_PROBE
+    __shared__ long ps_[8];
+    wg_unpack(a.desc, s_params, U, slot, T, true, false, false, true, ps_);
+    __syncthreads();
+    if (threadIdx.x == 0 && (int)(gs % f.NS) == 2) {
+        long *w = a.counters + 8 + a.C + 8 + 4; w[0] += ps_[1] - ps_[0]; w[1] += ps_[2] - ps_[1];
+        long *v = a.counters + 8 + a.C + 32; v[0] += ps_[5] - ps_[4]; v[1] += ps_[6] - ps_[5]; v[2] += ps_[7] - ps_[6]; v[3] += 1;
+    }
+#else
     wg_unpack(a.desc, s_params, U, slot, T, true, false, false, true);
+#endif
     if (threadIdx.x == 0) f.cand_stR[gs] = *U.status;
 }
 __device__ __attribute__((noinline)) void role_background(const DevSamplerArgs *ga, const FusedArgs *gf, int q_dst, int slot, int role,
@@ -1028,8 +1136,8 @@ __device__ __attribute__((noinline)) void role_background(const DevSamplerArgs *
     __syncthreads();
     TablePtrs T = candidate_tables(a, f, q_dst);
     T.bg = f.bg + (size_t)q_dst * f.NS * a.ntiles * bg::NH;
-    const int half = (a.ntiles + 1) / 2;
-    wg_bg_tiles(a.desc, s_params, U.S, slot, T, 0, 64, role == 2 ? 0 : half, role == 2 ? half : a.ntiles);
+    const int quarter = (a.ntiles + 3) / 4, k = role - 3;
+    wg_bg_tiles(a.desc, s_params, U.S, slot, T, 0, 64, k * quarter, (k + 1) * quarter);
 }
 
 // L z of chain `m` for iteration `itn` into f.lz[parity q_dst] (same streams, same row sums as propose_common), one wave.
@@ -1047,13 +1155,17 @@ __device__ __forceinline__ void lz_block(const DevSamplerArgs *ga, const FusedAr
     lz_rows(ga, gf, q_dst, m, s_z);
 }
 
-// One role of one candidate slot of iteration `itn`, by ONE wave.  Slot s < 2C: chain s/2, built on its current position (even) or
-// on its proposal of iteration itn-1 (odd); slots 2C..2C+3 (only when itn-1 swaps a pair A,B): chain A on B's two vectors, chain B on
-// A's two.  Roles: 0 = position + log-prior, 1 = table rows + noise row, 2 / 3 = background series of the lower / upper half of the
-// tiles.  Every role re-derives the proposal vector itself (no communication between the roles).
+// One role of one candidate slot of iteration `itn`, by ONE wave.  Slot s < 2C: chain s/2, built on the position it enters iteration
+// itn-1 with (even) or on its proposal of iteration itn-1 (odd); slots 2C..2C+3 (only when itn-1 swaps a pair A,B): chain A on B's two
+// vectors, chain B on A's two.  Roles: 0 = position + first half of the log-prior (and the hard constraints), 1 = table rows + noise row,
+// 2 = second half of the log-prior, 3..6 = background series of a quarter of the tiles each, 7 = none.  Every role re-derives the proposal vector itself (no communication between the roles), and -- inside a
+// stretch -- first decides iteration itn-2 for the chain it builds on (decide(): where that chain stands at itn-1, which slot it proposes).
+// entry: the candidates of iteration itn itself from the settled chains (state parity q_src), even slots only.
 __device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, const DevSamplerArgs *ga, const FusedArgs *gf, long itn, int q_src,
-                               int q_dst, int slot, int role, bool entry, unsigned char *lds) {
+                               int q_dst, int slot, int role, bool entry, int settled, int pairA, unsigned char *lds, Decided *dec) {
+    if (role > 6) return;
     const int C = a.C, Nv = a.Nv, Np = a.desc.Np, tid = threadIdx.x;
+    const int e_dst = (int)(itn % 3);
     int m, src, on_prop;
     if (slot < 2 * C) { m = slot >> 1; src = m; on_prop = slot & 1; }
     else {  // slot = 2C + e, e = 0..3: the pair's cross candidates, stored in the pair's extra block
@@ -1066,12 +1178,14 @@ __device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, cons
                                           // ahead of itself; the OTHER group's launches may be several iterations ahead)
     }
     if (entry && on_prop) return;  // a stretch starts from settled chains: there is no pending proposal to build on
-    if (role == 0 && slot < 2 * C && !on_prop && tid == 0) {  // housekeeping for the launch that evaluates these candidates
-        for (int g = 0; g <= NG; g++) f.ticket[((size_t)q_dst * C + m) * TK + g * TKS] = 0u;
-        // (by the first chain of iteration itn's swap pair: with chain groups that chain's launches are the ones that use the counter)
-        if (is_swap_iter(a, itn) && m == swap_first(a, itn, nullptr)) f.pair_ticket[2 * q_dst + (m >= f.xsplit ? 1 : 0)] = 0u;
-        if (entry) f.slot[q_dst * C + m] = 2 * m;
-    }
+    if (entry && role == 0 && tid == 0) f.slot[q_src * C + m] = 2 * m;
+#ifdef TAMCMC_PROBE
+    long pt[6];
+    pt[0] = (long)wall_clock64();
+#define RSTAMP(k) pt[k] = (long)wall_clock64()
+#else
+#define RSTAMP(k)
+#endif
     double *s_params = (double *)lds;
     double *s_vars = s_params + Np;
     double *s_z = s_vars + Nv;
@@ -1079,63 +1193,124 @@ __device__ void candidate_role(const DevSamplerArgs &a, const FusedArgs &f, cons
     __shared__ UnpackLds s_U;  // handed to the role functions by address
     if (tid == 0) s_U = U;
     const double *bv, *bp;
-    if (on_prop) {
-        const int ps = f.slot[q_src * C + src] & 0xffff;
-        bv = f.cand_vars + ((size_t)q_src * f.NS + ps) * Nv;
-        bp = f.cand_params + ((size_t)q_src * f.NS + ps) * Np;
-    } else {
+    if (entry) {
         bv = a.vars_cur + ((size_t)q_src * C + src) * Nv;
         bp = a.params_cur + ((size_t)q_src * C + src) * Np;
+    } else {
+        const int ps = quick_decide(ga, gf, src, itn - 1, q_src, settled, pairA, dec);
+        __syncthreads();
+        const Decided d = *dec;
+        if (on_prop) {  // src's proposal of iteration itn-1
+            const size_t gp = (size_t)((itn - 1) % 3) * f.NS + ps;
+            bv = f.cand_vars + gp * Nv;
+            bp = f.cand_params + gp * Np;
+        } else if (d.src_acc) {  // src enters iteration itn-1 at a proposal of iteration itn-2 that was accepted
+            const size_t gp = (size_t)((itn - 2) % 3) * f.NS + d.src_ps;
+            bv = f.cand_vars + gp * Nv;
+            bp = f.cand_params + gp * Np;
+        } else {
+            bv = a.vars_cur + ((size_t)d.src_par * C + d.src) * Nv;
+            bp = a.params_cur + ((size_t)d.src_par * C + d.src) * Np;
+        }
     }
-    for (int i = tid; i < Nv; i += 64) s_vars[i] = bv[i];
-    for (int i = tid; i < Np; i += 64) s_params[i] = bp[i];
-    const double *lz = f.lz + ((size_t)q_dst * C + m) * Nv;  // L z(itn) of chain m, computed one launch ahead (lz_block)
-    unpack_begin(a.desc, U);  // (barrier)
-    for (int i = tid; i < Nv; i += 64) s_vars[i] = s_vars[i] + 0.0 + lz[i];  // same expression as propose_common
-    __syncthreads();
-    for (int k = tid; k < Nv; k += 64) s_params[a.index_to_relax[k]] = s_vars[k];  // update_params_with_vars
-    __syncthreads();
-    const size_t gs = (size_t)q_dst * f.NS + slot;
+    RSTAMP(1);
+    // everything the proposal vector is made of in ONE memory round trip: the base vectors, L z(itn) of chain m (q_dst: iteration itn's
+    // parity; computed one launch ahead, lz_block), the scatter indices, the polynomial table
+    const double *lz = f.lz + ((size_t)q_dst * C + m) * Nv;
+    constexpr int PW = (int)(sizeof(mt::PolyTab) / sizeof(double));
+    if (Nv <= 128 && Np <= 128 && PW <= 256) {
+        double r_v[2], r_z[2], r_p[2], r_t[4];
+        int r_i[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int i = tid + 64 * e;
+            r_v[e] = i < Nv ? bv[i] : 0.0; r_z[e] = i < Nv ? lz[i] : 0.0; r_i[e] = i < Nv ? a.index_to_relax[i] : 0;
+            r_p[e] = i < Np ? bp[i] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int i = tid + 64 * e; r_t[e] = i < PW ? ((const double *)a.desc.poly)[i] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < 2; e++) { const int i = tid + 64 * e; if (i < Np) s_params[i] = r_p[e]; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int i = tid + 64 * e; if (i < PW) ((double *)U.poly)[i] = r_t[e]; }
+        if (tid == 0) { *U.status = TAMCMC_OK; *U.reject = 0; }  // (unpack_begin)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int i = tid + 64 * e;
+            if (i < Nv) { const double v = r_v[e] + 0.0 + r_z[e]; s_vars[i] = v; s_params[r_i[e]] = v; }  // same expression as propose_common; update_params_with_vars
+        }
+        __syncthreads();
+    } else {
+        for (int i = tid; i < Nv; i += 64) s_vars[i] = bv[i];
+        for (int i = tid; i < Np; i += 64) s_params[i] = bp[i];
+        unpack_begin(a.desc, U);  // (barrier)
+        for (int i = tid; i < Nv; i += 64) s_vars[i] = s_vars[i] + 0.0 + lz[i];
+        __syncthreads();
+        for (int k = tid; k < Nv; k += 64) s_params[a.index_to_relax[k]] = s_vars[k];
+        __syncthreads();
+    }
+    RSTAMP(2);
+    const size_t gs = (size_t)e_dst * f.NS + slot;
     // (three separate functions: inlined side by side the roles' code raises the whole kernel's register allocation above the
     // three-waves-per-SIMD budget of the tile path)
-    if (role == 0) role_prior(ga, gf, gs, s_vars, s_params, &s_U);
-    else if (role == 1) role_rows(ga, gf, q_dst, slot, gs, s_params, &s_U);
-    else role_background(ga, gf, q_dst, slot, role, s_params, &s_U);
+#ifdef TAMCMC_PROBE
+    if (a.probe & (0x100 << (role > 2 ? 2 : (role == 2 ? 0 : role)))) return;  // timing experiments: one kind of role left out
+#endif
+    if (role == 0 || role == 2) role_prior(ga, gf, gs, role >> 1, s_vars, s_params, &s_U);
+    else if (role == 1) role_rows(ga, gf, e_dst, slot, gs, s_params, &s_U);
+    else role_background(ga, gf, e_dst, slot, role, s_params, &s_U);
+#ifdef TAMCMC_PROBE
+    __syncthreads();
+    RSTAMP(3);
+    if (tid == 0 && slot == 2 && !entry && role < 4) {  // one slot's first four roles: decide | vectors, L z | the role itself (units of 10 ns)
+        long *w = a.counters + 8 + C + 8 * role;
+        w[0] += pt[1] - pt[0]; w[1] += pt[2] - pt[1]; w[2] += pt[3] - pt[2]; w[3] += 1;
+    }
+#endif
+#undef RSTAMP
 }
 
 // Per-launch scalars of the fused step.
 struct StepCtl {
-    long it, rec, it_lz;   // iteration of the tiles / candidates; record index (-1: none); first iteration of the L z blocks
+    long it, rec, it_lz;   // iteration of the tiles; record index of iteration it-1 (-1: none); first iteration of the L z blocks
     int q, flags;          // parity of iteration `it`; ST_* bits
-    int nbr, nlz;          // workgroups reserved for candidate roles / L z blocks (multiples of 8: keeps the tiles' XCD mapping)
+    int nbr, nlz;          // workgroups reserved for candidate roles / L z blocks + commits (multiples of 8: keeps the tiles' XCD mapping)
     int n_lz_live, q_lz;   // L z blocks that have work (chain first + e % cnt of iteration it_lz + e / cnt); parity of it_lz
     int first, cnt;        // the chains of this launch: [first, first + cnt) -- all of them, or one chain group (see run(): fused)
     int extra;             // 1: the launch also builds the four extra candidates of its iteration's swap pair (slots 2C..2C+3)
-    const DevSamplerArgs *ga;  // device-memory copies of the first two kernel arguments (for the candidate roles' function calls)
+    int pairA;             // first chain of iteration it-1's swap pair, -1: none (quick_slot)
+    const DevSamplerArgs *ga;  // device-memory copies of the first two kernel arguments (for the function calls)
     const struct FusedArgs *gf;
 };
 
 // Launch `it` of a fused stretch: [0, nbr) candidate roles of iteration it+1 (ST_BR; at the entry of a stretch, ST_ENTRY: of iteration
-// `it` itself from the settled chains), [nbr, nbr+nlz) L z of later iterations (ST_LZ), then the likelihood tiles of iteration `it` (ST_L).
+// `it` itself from the settled chains), [nbr, nbr+nlz): L z of later iterations (ST_LZ) and, in the last cnt of them, the chains' commit
+// workgroups (ST_COMMIT), then the likelihood tiles of iteration `it` (ST_L).  ST_FIRST: the chains are settled (nothing to decide).
 #define TAMCMC_STEP_BODY                                                                                                      \
     __shared__ tile::TileLds<MODE, 64> lds;                                                                                  \
+    __shared__ Decided s_dec;                                                                                                \
     const int id = (int)blockIdx.x;                                                                                          \
+    const int settled = (c.flags & ST_FIRST) ? 1 : 0;                                                                        \
+    /* the few single-wave workgroups with long dependent chains (roles, L z, commit) issue ahead of the tiles they share a SIMD with */ \
+    if (id < c.nbr + c.nlz) __builtin_amdgcn_s_setprio(3);                                                                   \
     if (id < c.nbr) {                                                                                                        \
-        const int k = id >> 2, slot = k < 2 * c.cnt ? 2 * c.first + k : 2 * a.C + (k - 2 * c.cnt); /* the group's slots, then the pair's */ \
+        const int k = id >> 3, slot = k < 2 * c.cnt ? 2 * c.first + k : 2 * a.C + (k - 2 * c.cnt); /* the group's slots, then the pair's */ \
         if (k >= 2 * c.cnt && !c.extra) return;                                                                              \
-        if (c.flags & ST_ENTRY) candidate_role(a, f, c.ga, c.gf, c.it, c.q, c.q, slot, id & 3, true, (unsigned char *)&lds);    \
+        if (c.flags & ST_ENTRY) candidate_role(a, f, c.ga, c.gf, c.it, c.q, c.q, slot, id & 7, true, 1, -1, (unsigned char *)&lds, &s_dec);    \
         else if (c.flags & ST_BR)                                                                                            \
-            candidate_role(a, f, c.ga, c.gf, c.it + 1, c.q, c.q ^ 1, slot, id & 3, false, (unsigned char *)&lds);              \
+            candidate_role(a, f, c.ga, c.gf, c.it + 1, c.q, c.q ^ 1, slot, id & 7, false, settled, c.pairA, (unsigned char *)&lds, &s_dec); \
         return;                                                                                                              \
     }                                                                                                                        \
     if (id < c.nbr + c.nlz) {                                                                                                \
-        const int e = id - c.nbr;                                                                                            \
-        if (e < c.n_lz_live)                                                                                                 \
+        const int e = id - c.nbr, k = e - (c.nlz - c.cnt);                                                                   \
+        if (k >= 0 && (c.flags & ST_COMMIT)) commit_chain(c.ga, c.gf, c.first + k, c.it, c.q, settled, c.rec, &s_dec);       \
+        else if (e < c.n_lz_live)                                                                                            \
             lz_block(c.ga, c.gf, c.it_lz + e / c.cnt, (c.q_lz ^ (e / c.cnt)) & 1, c.first + e % c.cnt, (unsigned char *)&lds);  \
         return;                                                                                                              \
     }                                                                                                                        \
     if (c.flags & ST_L)                                                                                                      \
-        tile::loglike_tile<MODE, 64, K, false, false>(la, id - c.nbr - c.nlz, lds, SettleTail{a, f, c.ga, c.gf, c.it, c.rec, c.q, c.first});
+        tile::loglike_tile<MODE, 64, K, false, false>(la, id - c.nbr - c.nlz, lds, StepTiles{c.ga, c.gf, c.it, c.q, c.first, settled, c.pairA});
 // The tile path of K <= 8 bins per lane fits 168 VGPRs = three waves per SIMD; the candidate roles (log-prior, series) would raise the
 // kernel's allocation above that, so the occupancy is pinned here (those roles are separate functions, see candidate_role).
 template <int MODE, int K>
@@ -1199,7 +1374,7 @@ struct DevSampler::Impl {
     FdBatch fd;
     DevBuf<unsigned char> fd_block;
     DevBuf<double> fd_part, fd_S, fd_model, fd_bg;
-    DevBuf<double> fused_bg;  // (A): the candidates' background series (see run())
+    DevBuf<double> fused_bg, fused_part;  // (A): the candidates' background series, the tiles' partial sums by parity (see run())
     MalaArgs mala{};
     bool grad_valid = false;
     int prior_class = 0, model_id = 0;
@@ -1280,6 +1455,16 @@ DevSampler::~DevSampler() {
         for (int g = 1; g < 4; g++) if (impl->gst[g]) (void)hipStreamSynchronize(impl->gst[g]);
     }
 #ifdef TAMCMC_PROBE
+    if (impl->a.counters && getenv("TAMCMC_PROBE_STEP")) {
+        long h[40];
+        (void)hipMemcpy(h, impl->a.counters + 8 + impl->a.C, sizeof h, hipMemcpyDeviceToHost);
+        if (h[35] > 0) fprintf(stderr, "build_multiplet, row 20 (us): decode + widths/heights %.2f | window %.2f | m loop %.2f\n", 0.01 * h[32] / h[35], 0.01 * h[33] / h[35], 0.01 * h[34] / h[35]);
+        for (int r = 0; r < 4; r++)
+            if (h[8 * r + 3] > 0)
+                fprintf(stderr, "candidate role %d of slot 2 (us): decide %.2f | vectors + L z %.2f | role %.2f  [inside: %.2f | %.2f]  (%ld launches)\n", r,
+                        0.01 * h[8 * r] / h[8 * r + 3], 0.01 * h[8 * r + 1] / h[8 * r + 3], 0.01 * h[8 * r + 2] / h[8 * r + 3],
+                        0.01 * h[8 * r + 4] / h[8 * r + 3], 0.01 * h[8 * r + 5] / h[8 * r + 3], h[8 * r + 3]);
+    }
     if (impl->a.counters && getenv("TAMCMC_PROBE_ADAPT")) {
         long h[8];
         (void)hipMemcpy(h, impl->a.counters, sizeof h, hipMemcpyDeviceToHost);
@@ -1289,7 +1474,7 @@ DevSampler::~DevSampler() {
     }
 #endif
     for (void *p : impl->allocs) (void)hipFree(p);
-    impl->fd_block.release(); impl->fd_part.release(); impl->fd_S.release(); impl->fd_model.release(); impl->fd_bg.release(); impl->fused_bg.release();
+    impl->fd_block.release(); impl->fd_part.release(); impl->fd_S.release(); impl->fd_model.release(); impl->fd_bg.release(); impl->fused_bg.release(); impl->fused_part.release();
     if (impl->h_pack) (void)hipHostFree(impl->h_pack);
     for (int i = 0; i < impl->n_ev; i++) { (void)hipEventDestroy(impl->ev[i][0]); (void)hipEventDestroy(impl->ev[i][1]); }
     for (int i = 0; i < impl->n_gev; i++) { (void)hipEventDestroy(impl->gev[i][0]); (void)hipEventDestroy(impl->gev[i][1]); }
@@ -1372,7 +1557,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.vars_prop, 2 * CD * Nv)); DCHK(I.dalloc(&a.params_prop, 2 * CD * Np));
     DCHK(I.dalloc(&a.logL_cur, 2 * C)); DCHK(I.dalloc(&a.logPr_cur, 2 * C)); DCHK(I.dalloc(&a.logPost_cur, 2 * C));
     DCHK(I.dalloc(&a.init_logL, C)); DCHK(I.dalloc(&a.logPr_prop, 2 * CD)); DCHK(I.dalloc(&a.status_prop, 2 * CD));
-    DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8 + C));
+    DCHK(I.dalloc(&a.Pmove, C)); DCHK(I.dalloc(&a.moved, C)); DCHK(I.dalloc(&a.counters, 8 + C + 64));  // (+64: timeline stamps of the probe build)
     a.grad_cur = nullptr; a.gradP_cur = nullptr;
     if (I.use_drift) {
         DCHK(I.dalloc(&a.grad_cur, 2 * C * Nv)); DCHK(I.dalloc(&a.gradP_cur, 2 * C * Nv));
@@ -1382,7 +1567,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
     DCHK(I.dalloc(&a.lz, 2 * C * Nv)); DCHK(I.dalloc(&a.LT, C * Nv * Nv)); DCHK(I.dalloc(&a.cov, C * Nv * Nv)); DCHK(I.dalloc(&a.mu, C * Nv)); DCHK(I.dalloc(&a.sigma, C));
     DCHK(I.dalloc(&a.mults, CD * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&a.pairs, 2 * CD)); DCHK(I.dalloc(&a.nh, CD)); DCHK(I.dalloc(&a.nn, CD));
     DCHK(I.dalloc(&a.noise, CD * (size_t)a.desc.stride));
-    DCHK(hipMemsetAsync(a.counters, 0, (8 + C) * sizeof(long), st));
+    DCHK(hipMemsetAsync(a.counters, 0, (8 + C + 64) * sizeof(long), st));
     DCHK(hipMemsetAsync(a.moved, 0, C * sizeof(int), st));
     DCHK(hipMemsetAsync(a.Pmove, 0, C * sizeof(double), st));
     a.samples = nullptr; a.stats = nullptr;
@@ -1415,7 +1600,7 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
         }
         I.ev_made = true;
     }
-    {  // (A) fused step: 2C+4 candidate slots per iteration parity, tickets, outcomes (tables are sized at the first run())
+    {  // (A) fused step: three sets (iteration mod 3) of 2C+8 candidate slots, per-chain hand-over arrays by parity (tables are sized at the first run())
         FusedArgs &f = I.f;
         f.NS = 2 * in.C + 8;
         {   // two chain groups for the fused step (see run()): with the default groups, from 8 chains on
@@ -1423,14 +1608,16 @@ int DevSampler::init(tamcmc_hip_ctx *c, const DevSamplerInit &in) {
             f.xsplit = (I.G == 2 && h >= 3 && in.C - h >= 3) ? h : in.C;
         }
         const size_t NS = (size_t)f.NS;
-        DCHK(I.dalloc(&f.cand_vars, 2 * NS * Nv)); DCHK(I.dalloc(&f.cand_params, 2 * NS * Np)); DCHK(I.dalloc(&f.cand_logPr, 2 * NS));
-        DCHK(I.dalloc(&f.cand_stP, 2 * NS)); DCHK(I.dalloc(&f.cand_stR, 2 * NS));
-        DCHK(I.dalloc(&f.mults, 2 * NS * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&f.pairs, 4 * NS)); DCHK(I.dalloc(&f.nh, 2 * NS)); DCHK(I.dalloc(&f.nn, 2 * NS));
-        DCHK(I.dalloc(&f.noise, 2 * NS * (size_t)a.desc.stride));
-        DCHK(I.dalloc(&f.slot, 2 * C)); DCHK(I.dalloc(&f.ticket, 2 * C * TK)); DCHK(I.dalloc(&f.lz, 2 * C * Nv)); DCHK(I.dalloc(&f.pair_ticket, 4)); DCHK(I.dalloc(&f.acc, 2 * C * 5));
-        DCHK(hipMemsetAsync(f.nn, 0, 2 * NS * sizeof(int), st));
-        DCHK(hipMemsetAsync(f.cand_stP, 0, 2 * NS * sizeof(int), st));
-        DCHK(hipMemsetAsync(f.cand_stR, 0, 2 * NS * sizeof(int), st));
+        DCHK(I.dalloc(&f.cand_vars, 3 * NS * Nv)); DCHK(I.dalloc(&f.cand_params, 3 * NS * Np)); DCHK(I.dalloc(&f.cand_logPr, 6 * NS));
+        DCHK(I.dalloc(&f.cand_stP, 6 * NS)); DCHK(I.dalloc(&f.cand_stR, 3 * NS)); DCHK(I.dalloc(&f.cand_rej, 3 * NS));
+        DCHK(I.dalloc(&f.mults, 3 * NS * (size_t)a.desc.per + 1)); DCHK(I.dalloc(&f.pairs, 6 * NS)); DCHK(I.dalloc(&f.nh, 3 * NS)); DCHK(I.dalloc(&f.nn, 3 * NS));
+        DCHK(I.dalloc(&f.noise, 3 * NS * (size_t)a.desc.stride));
+        DCHK(I.dalloc(&f.slot, 2 * C)); DCHK(I.dalloc(&f.prop_logPr, 2 * C)); DCHK(I.dalloc(&f.prop_st, 2 * C)); DCHK(I.dalloc(&f.quick, 2 * C * QN)); DCHK(I.dalloc(&f.lz, 2 * C * Nv));
+        DCHK(hipMemsetAsync(f.nn, 0, 3 * NS * sizeof(int), st));
+        DCHK(hipMemsetAsync(f.cand_stP, 0, 6 * NS * sizeof(int), st));
+        DCHK(hipMemsetAsync(f.cand_rej, 0, 3 * NS * sizeof(int), st));
+        DCHK(hipMemsetAsync(f.cand_stR, 0, 3 * NS * sizeof(int), st));
+        f.part = nullptr;
         f.bg = nullptr;
         // the candidate roles borrow the tile workgroup's LDS: a parameter vector too long for it keeps the lockstep scheme
         const size_t role_lds = (Np + 2 * Nv + 1) * sizeof(double) + unpack_lds_bytes() + 32;
@@ -1626,9 +1813,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         DCHK(c->d_bg.reserve(C * (size_t)a.ntiles * 8));
         a.bg = c->d_bg.p;
         if (use_fused) {
-            DCHK(I.fused_bg.reserve(2 * NS * (size_t)a.ntiles * 8));
+            DCHK(I.fused_bg.reserve(3 * NS * (size_t)a.ntiles * 8));
             I.f.bg = I.fused_bg.p;
         }
+    }
+    if (use_fused) {  // (A): the tiles' partial sums by iteration parity (launch i writes one half and reads the other)
+        DCHK(I.fused_part.reserve(2 * C * (size_t)a.ntiles * 2));
+        I.f.part = I.fused_part.p;
     }
     // record buffers: at least 256 iterations' worth and grown geometrically, so that a caller that records in buffers of a fixed
     // length (the reference's Nbuffer) or a short call after a shorter one never pays an allocation -- nor, with it, new kernel
@@ -1653,7 +1844,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     int goff[5];
     for (int g = 0; g <= G; g++) goff[g] = (int)(((long)a.C * g) / G);
     auto group_of = [&](int chain) { int g = 0; while (g + 1 < G && chain >= goff[g + 1]) g++; return g; };
-    LoglikeArgs la[4], lf[2];
+    LoglikeArgs la[4], lf[3];
     auto fill_common = [&](LoglikeArgs &l, int B) {
         l.x = c->dx.p; l.y = c->dy.p; l.logx = c->dlogx.p; l.Nx = a.desc.Nx; l.B = B; l.ntiles = a.ntiles;
         l.x0 = a.desc.x_first; l.step = a.desc.step; l.noise_stride = a.desc.stride; l.model = nullptr; l.tile_rot = I.tile_rot;
@@ -1667,14 +1858,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         l.nharvey = a.nh + first; l.nnoise = a.nn + first; l.partials = a.partials + (size_t)first * a.ntiles * 2;
         l.bg_poly = a.bg ? a.bg + (size_t)first * a.ntiles * 8 : nullptr;
     }
-    for (int q = 0; q < 2; q++) {  // (A): evaluation m = chain m, its table in slot f.slot[q][m] of parity q's candidate block
-        LoglikeArgs &l = lf[q];
+    for (int e = 0; e < 3; e++) {  // (A): evaluation m = chain m, its table in a slot of candidate set e = iteration mod 3 (decide())
+        LoglikeArgs &l = lf[e];
         const FusedArgs &f = I.f;
         fill_common(l, a.C);
-        l.mults = f.mults + (size_t)q * NS * a.desc.per; l.offsets = f.pairs + (size_t)q * 2 * NS; l.noise = f.noise + (size_t)q * NS * a.desc.stride;
-        l.nharvey = f.nh + (size_t)q * NS; l.nnoise = f.nn + (size_t)q * NS; l.partials = a.partials;
-        l.bg_poly = f.bg ? f.bg + (size_t)q * NS * a.ntiles * 8 : nullptr;
-        l.slot_map = f.slot + (size_t)q * C;
+        l.mults = f.mults + (size_t)e * NS * a.desc.per; l.offsets = f.pairs + (size_t)e * 2 * NS; l.noise = f.noise + (size_t)e * NS * a.desc.stride;
+        l.nharvey = f.nh + (size_t)e * NS; l.nnoise = f.nn + (size_t)e * NS; l.partials = f.part;
+        l.bg_poly = f.bg ? f.bg + (size_t)e * NS * a.ntiles * 8 : nullptr;
         l.per = a.desc.per; l.slot0 = 0;
     }
 
@@ -1795,7 +1985,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     // ---- (A) fused steps over [ia, ib) (no adaptation inside): one launch per iteration on the context stream, or two (one per chain group)
     auto fused = [&](long ia, long ib) -> int {
         const FusedArgs &f = I.f;
-        const int nbr = 4 * f.NS;                                     // candidate roles, a multiple of 8 (keeps the tiles' XCD mapping)
+        const int nbr = 8 * f.NS;                                     // candidate roles, a multiple of 8 (keeps the tiles' XCD mapping)
         const int nlz2 = ((2 * a.C + 7) / 8) * 8;
         const int ntiles_pad = ((a.ntiles + 7) / 8) * 8;
         const long len = ib - ia;
@@ -1826,9 +2016,9 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             st_has_work = true;
             // entry: L z of the first two iterations, then the candidates of iteration ia built on the settled chains (state of parity q)
             sc.it = it0 + ia; sc.rec = -1; sc.q = q; sc.flags = ST_LZ; sc.nbr = 0; sc.nlz = nlz2; sc.n_lz_live = 2 * a.C; sc.it_lz = it0 + ia; sc.q_lz = q;
-            DCHK(launch_step(c->precision, c->K, nlz2, st, args, f, lf[q], sc));
+            DCHK(launch_step(c->precision, c->K, nlz2, st, args, f, lf[0], sc));
             sc.flags = ST_ENTRY; sc.nbr = nbr; sc.nlz = 0; sc.n_lz_live = 0;
-            DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[q], sc));
+            DCHK(launch_step(c->precision, c->K, nbr, st, args, f, lf[0], sc));
         }
         // the likelihood kernel's time for the roofline: two events around the whole stretch, i.e. the average includes the time between
         // two launches
@@ -1836,13 +2026,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         const int fe = I.n_ev - 1 - (int)fused_ev.size();
         // (it pays once one launch no longer fits the GPU's resident waves -- 20 chains x 196 tiles: 27.7 -> 23.9 us, x 782 tiles: 59.8 ->
         // 49.6 us -- and costs below that: 8 chains x 196 tiles 20.5 -> 23.7 us, 20 chains x 20 tiles 33.5 -> 35.6 us; tools/groups_probe.py)
-        const bool split = f.xsplit < a.C && c->step_scheme != 2 && (c->step_scheme == 3 || (long)a.C * a.ntiles >= 2500);
+        const bool split_ok = f.xsplit < a.C && c->step_scheme != 2 && (c->step_scheme == 3 || (long)a.C * a.ntiles >= 2500);
+        const bool split = split_ok;
         if (timed && !split) DCHK(hipEventRecord(I.ev[fe][0], st));
-        // Two chain groups, each with its own launch per iteration on its own stream: a launch is a chain of dependent steps (slot ->
-        // table rows -> tile -> ticket -> settle, ~20 us even for five chains) that leaves most of the GPU idle at its two ends; the two
-        // groups' launches fill each other's ends (two 10-chain stars side by side: 24.2 us per iteration each, one 20-chain launch: 27.8).
-        // Nothing is shared between the groups' launches except at a swap whose pair straddles the groups: that iteration is ONE launch
-        // over all chains on the context stream, with an event each way.  (Same chains bit for bit: the launches' contents are the same.)
+        // Two chain groups, each with its own launch per iteration on its own stream: a launch is a chain of dependent steps (sums ->
+        // decision -> table rows -> tile, ~18 us even for five chains) that leaves most of the GPU idle at its two ends; the two
+        // groups' launches fill each other's ends.  Nothing is shared between the groups' launches except at a swap whose pair straddles
+        // the groups: see straddles() below.  (Same chains bit for bit: the launches' contents are the same.)
         const int first1 = f.xsplit;
         hipStream_t s1 = I.gst[1];
         long n_split = 0;
@@ -1855,33 +2045,59 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
             if (A > a.C - 2) A = a.C - 2;
             return A;
         };
-        auto launch_group = [&](int first, int cnt, int A, long i, hipStream_t stream, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) -> int {
-            // every launch also prepares the next iteration's candidates and the L z after that -- the last one too (see armed_it)
+        // Launch i of a stretch: the tiles of iteration i (each decides iteration i-1 for its chain first), the chains' commit workgroups
+        // (state, record and counters of iteration i-1), the candidates of iteration i+1, the L z of iteration i+2.  settled: the chains
+        // are settled (first launch of a stretch: nothing to decide or commit).
+        auto launch_group = [&](int first, int cnt, int A, long i, bool settled, hipStream_t stream, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) -> int {
             const bool owns_pair = A >= first && A + 1 < first + cnt;
-            sc.it = it0 + i; sc.rec = (samples || stats) ? i : (long)-1; sc.q = q;
-            sc.flags = ST_L | ST_BR | ST_LZ;
-            sc.first = first; sc.cnt = cnt; sc.extra = owns_pair ? 1 : 0;
-            sc.nbr = 4 * (2 * cnt + (owns_pair ? 4 : 0)); sc.nlz = ((cnt + 7) / 8) * 8; sc.n_lz_live = cnt; sc.it_lz = it0 + i + 2; sc.q_lz = q;
-            LoglikeArgs lq = lf[q];
+            sc.it = it0 + i; sc.rec = ((samples || stats) && !settled) ? i - 1 : (long)-1; sc.q = q;
+            sc.flags = ST_L | ST_BR | ST_LZ | ST_COMMIT | (settled ? ST_FIRST : 0);
+#ifdef TAMCMC_PROBE  // timing experiments only (results are wrong): leave kinds of workgroups out of the launch
+            if (const char *ep = getenv("TAMCMC_PROBE_STEP")) {
+                const int pm = atoi(ep);
+                if (pm & 1) sc.flags &= ~ST_BR;
+                if (pm & 2) sc.flags &= ~ST_COMMIT;
+                if (pm & 4) sc.flags &= ~ST_LZ;
+                if (pm & 8) sc.flags |= ST_FIRST;
+                if (pm & 16) sc.flags &= ~ST_L;
+            }
+#endif
+            sc.first = first; sc.cnt = cnt; sc.extra = owns_pair ? 1 : 0; sc.pairA = settled ? -1 : swap_pair_of(it0 + i - 1);
+            sc.nbr = 8 * (2 * cnt + (owns_pair ? 4 : 0)); sc.nlz = ((2 * cnt + 7) / 8) * 8; sc.n_lz_live = cnt; sc.it_lz = it0 + i + 2; sc.q_lz = q;
+            LoglikeArgs lq = lf[(it0 + i) % 3];
             lq.B = cnt;
-            lq.slot_map = lf[q].slot_map + first;
-            lq.partials = lf[q].partials + (size_t)first * a.ntiles * 2;
-            if (owns_pair && cnt >= 3) lq.prio_b = A - first;  // this iteration's swap pair leads the launch
+            lq.partials = f.part + ((size_t)q * a.C + first) * a.ntiles * 2;
             DCHK(launch_step(c->precision, c->K, sc.nbr + sc.nlz + ntiles_pad * cnt, stream, args, f, lq, sc, e0, e1));
             return TAMCMC_OK;
         };
+        // After the last iteration of a stretch: the commit workgroups alone (iteration ib-1 decided, the chains settled in parity q).
+        auto launch_close = [&](int first, int cnt, hipStream_t stream) -> int {
+            sc.it = it0 + ib; sc.rec = (samples || stats) ? ib - 1 : (long)-1; sc.q = q;
+            sc.flags = ST_COMMIT;
+            sc.first = first; sc.cnt = cnt; sc.extra = 0;
+            sc.nbr = 0; sc.nlz = ((cnt + 7) / 8) * 8; sc.n_lz_live = 0; sc.it_lz = 0; sc.q_lz = 0;
+            DCHK(launch_step(c->precision, c->K, sc.nlz, stream, args, f, lf[0], sc));
+            return TAMCMC_OK;
+        };
+        // A swap whose pair straddles the two groups: the launch of that iteration builds the pair's cross candidates on both chains'
+        // vectors, the next one decides the swap from both chains' sums and commits each side from the other's vectors -- those two
+        // launches are joint (all chains, on the context stream, after both groups' earlier launches)
+        auto straddles = [&](int A) { return split_ok && A == first1 - 1; };
         for (long i = ia; i < ib; i++) {
             const int A = swap_pair_of(it0 + i);
-            if (split && A != first1 - 1) {
+            const bool settled = i == ia;
+            const bool joint = !split_ok || straddles(A) || (!settled && straddles(swap_pair_of(it0 + i - 1)));
+            if (!joint) {
                 if (s1_must_wait) {
                     DCHK(hipEventRecord(I.ev_fork, st));
                     DCHK(hipStreamWaitEvent(s1, I.ev_fork, 0));
                     s1_must_wait = false;
                 }
-                int rc = launch_group(0, first1, A, i, st);
+                int rc = launch_group(0, first1, A, i, settled, st);
                 if (rc) return rc;
                 const bool sample = timed && g_used < I.n_gev && (len >= 97 ? ((i - ia) % 97 == 48) : (i - ia == len / 2));
-                rc = sample ? launch_group(first1, a.C - first1, A, i, s1, I.gev[g_used][0], I.gev[g_used][1]) : launch_group(first1, a.C - first1, A, i, s1);
+                rc = sample ? launch_group(first1, a.C - first1, A, i, settled, s1, I.gev[g_used][0], I.gev[g_used][1])
+                            : launch_group(first1, a.C - first1, A, i, settled, s1);
                 if (rc) return rc;
                 if (sample) g_used++;
                 s1_ahead = true;
@@ -1892,11 +2108,20 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
                     DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
                     s1_ahead = false;
                 }
-                int rc = launch_group(0, a.C, A, i, st);
+                int rc = launch_group(0, a.C, A, i, settled, st);
                 if (rc) return rc;
                 s1_must_wait = true;
             }
             q ^= 1;
+        }
+        if (s1_ahead) {  // (the last launches were one per group: iteration ib-1's swap pair lies inside one of them)
+            int rc = launch_close(0, first1, st);
+            if (rc) return rc;
+            rc = launch_close(first1, a.C - first1, s1);
+            if (rc) return rc;
+        } else {
+            int rc = launch_close(0, a.C, st);
+            if (rc) return rc;
         }
         if (s1_ahead) {
             if (ib >= n_iter) s1_open = true;  // the call's last stretch: the host waits for both streams below (no event hop on the GPU)

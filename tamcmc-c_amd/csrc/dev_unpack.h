@@ -75,40 +75,51 @@ __device__ inline void unpack_begin(const ModelDesc &d, const UnpackLds &u) {
 }
 
 // m-visibilities (function_rot.cpp): one lane per TERM of each Wigner sum d^l_{i,0}(beta), i=0..l, and of the centre
-// elements d^l_{0,0}(-beta); slot layout: for l=1..3, for i=0..l, then the centre (i=0, -beta): terms s=0..l-i (28).
-// Each lane first FINDS its (l, i, s), then all lanes evaluate their term together (no divergent calls).
+// elements d^l_{0,0}(-beta); slot layout: for l=1..3, for i=0..l, then the centre (i=0, -beta): terms s=0..l-i (28 slots, 12 elements).
+// Which (l, i, s) a lane owns and where an element's terms begin are compile-time tables packed into 64-bit constants (two or five
+// bits per entry): no search loop, no memory access -- this stage sits on the longest dependent chain of the sampler's fused step.
 // `lane` = index within the cooperating lanes (>= 28 of them), `sync` = their barrier: __syncthreads() for a whole
 // workgroup, a wavefront fence when ONE wave does the stage beside the others (LDS operations of a wave complete in order).
+namespace vis {
+struct Pack {
+    unsigned long long l, i, s, neg;  // per term slot: degree, row, term index (2 bits each); the centre's -beta (1 bit)
+    unsigned long long first, el, ei; // per element: first term slot (5 bits), degree, row (2 bits each)
+};
+constexpr Pack make_pack() {
+    Pack p{0, 0, 0, 0, 0, 0, 0};
+    int sl = 0, el = 0;
+    for (int l = 1; l <= 3; l++)
+        for (int e = 0; e <= l + 1; e++) {
+            const int i = (e <= l) ? e : 0;
+            p.first |= (unsigned long long)sl << (5 * el);
+            p.el |= (unsigned long long)l << (2 * el);
+            p.ei |= (unsigned long long)i << (2 * el);
+            el++;
+            for (int s = 0; s <= l - i; s++, sl++) {
+                p.l |= (unsigned long long)l << (2 * sl);
+                p.i |= (unsigned long long)i << (2 * sl);
+                p.s |= (unsigned long long)s << (2 * sl);
+                if (e > l) p.neg |= 1ull << sl;
+            }
+        }
+    return p;
+}
+}  // namespace vis
 template <class Sync>
 __device__ inline void visibilities_stage(const UnpackLds &u, int lane, Sync sync) {
     mt::Shared *S = u.S;
-    {
+    constexpr vis::Pack P = vis::make_pack();
+    if (lane < 28) {
         const double PI = 3.141592653589793238462643;
         const double ang = PI * S->inc / 180.;
-        int sl = 0, my_l = 0, my_i = 0, my_s = 0;
-        double my_b = 0;
-        for (int l = 1; l <= 3; l++)
-            for (int e = 0; e <= l + 1; e++) {
-                const int i = (e <= l) ? e : 0;
-                for (int s = 0; s <= l - i; s++, sl++)
-                    if (sl == lane) { my_l = l; my_i = i; my_s = s; my_b = (e <= l) ? ang : -ang; }
-            }
-        if (my_l > 0 && S->need_ratio[my_l]) u.w[lane] = mt::wigner_term(my_l, my_i, 0, my_b, my_s);
+        const int my_l = (int)((P.l >> (2 * lane)) & 3), my_i = (int)((P.i >> (2 * lane)) & 3), my_s = (int)((P.s >> (2 * lane)) & 3);
+        const double my_b = ((P.neg >> lane) & 1) ? -ang : ang;
+        if (S->need_ratio[my_l]) u.w[lane] = mt::wigner_term(my_l, my_i, 0, my_b, my_s);
     }
     sync();
     if (lane < 12) {  // one lane per ELEMENT: sum its terms in order, normalise (dmm's tail)
-        int l = 1, e = lane;
-        if (lane >= 3) { l = 2; e = lane - 3; }
-        if (lane >= 7) { l = 3; e = lane - 7; }
+        const int l = (int)((P.el >> (2 * lane)) & 3), i = (int)((P.ei >> (2 * lane)) & 3), sl = (int)((P.first >> (5 * lane)) & 31);
         if (S->need_ratio[l]) {
-            int sl = 0;
-            for (int ll = 1; ll <= l; ll++)
-                for (int ee = 0; ee <= ll + 1; ee++) {
-                    if (ll == l && ee == e) goto found;
-                    sl += ll - ((ee <= ll) ? ee : 0) + 1;
-                }
-        found:
-            const int i = (e <= l) ? e : 0;
             double sum = 0;
             for (int s = 0; s <= l - i; s++) sum = sum + u.w[sl + s];
             u.w[28 + lane] = mt::wigner_finish(l, i, 0, sum);
@@ -210,23 +221,35 @@ __device__ inline double wg_log_prior(const ModelDesc &d, const double *s_params
     return *u.reject ? -INFINITY : f;
 }
 
-// The same log-prior by ONE wave (blockDim.x == 64), bit for bit the value wg_log_prior returns in the proposal kernel's 256-thread
+#ifdef TAMCMC_PROBE
+#define UPSTAMP(k) do { if (pst) pst[k] = (long)wall_clock64(); } while (0)
+#else
+#define UPSTAMP(k)
+#endif
+// The same log-prior by single waves (blockDim.x == 64), bit for bit the value wg_log_prior returns in the proposal kernel's 256-thread
 // layout: there `virt` (= 128) lanes take the additive terms (term t on lane t mod virt, in increasing t), each wave of 64 lanes sums
-// its lanes with a shuffle tree and the waves are added in order.  Here every lane plays virt/64 virtual lanes, one after the other.
-__device__ inline double wave_log_prior(const ModelDesc &d, const double *s_params, const UnpackLds &u, int virt) {
+// its lanes with a shuffle tree and the waves are added in order.  Here ONE wave plays the lanes [64 h, 64 h + 64) of that layout and
+// returns their sum; the caller adds the halves in order (h = 0, 1, ..).  Half 0 also checks the hard constraints (*rejected: the
+// log-prior is -inf whatever the sums).  Two waves instead of one that plays both halves: each is on the fused step's longest chain.
+__device__ inline double wave_log_prior_part(const ModelDesc &d, const double *s_params, const UnpackLds &u, int virt, int h, int *rejected,
+                                             long *pst = nullptr) {
     const int Np = d.Np, tid = threadIdx.x;
+    const int n_extra = (d.prior_class == 2) ? pr::ms_global_extra_terms(d.plength, d.extra) : 0;
+    UPSTAMP(0);
+    bool need_dnu = false;  // does this half hold a term that needs the large separation?  (virt is a power of two: 128)
+    for (int t = Np; t < Np + n_extra; t++) need_dnu = need_dnu || (((t & (virt - 1)) >> 6) == h);
     {
         int st = TAMCMC_OK;
         mt::xreal c = 0;
         if (d.prior_class == 2) {
-            c = pr::ms_global_constraints(s_params, d.plength, d.priors_switch, d.extra, &st, tid, 64);
-            if (tid == 1) {
+            if (h == 0) c = pr::ms_global_constraints(s_params, d.plength, d.priors_switch, d.extra, &st, tid, 64);
+            if (need_dnu && tid == (h == 0 ? 1 : 0)) {
                 double fit[2];
                 mt::linfit_index(s_params + d.plength[0] + d.plength[1], d.plength[2], fit);
                 *u.dnu = fit[0];
             }
         } else if (d.prior_class == 3) {
-            if (tid == 0) c = pr::local_constraints(s_params, d.plength, d.priors_switch, d.extra);
+            if (h == 0 && tid == 0) c = pr::local_constraints(s_params, d.plength, d.priors_switch, d.extra);
         } else {
             c = pr::neg_inf();
             st = TAMCMC_ERR_BAD_MODEL;
@@ -235,34 +258,34 @@ __device__ inline double wave_log_prior(const ModelDesc &d, const double *s_para
         if (st != TAMCMC_OK) *u.status = st;
     }
     __syncthreads();
-    const int n_extra = (d.prior_class == 2) ? pr::ms_global_extra_terms(d.plength, d.extra) : 0;
+    UPSTAMP(1);
     int st = TAMCMC_OK;
-    double total = 0;
-    for (int h = 0; h * 64 < virt; h++) {
-        double f = 0;
-        for (int t = h * 64 + tid; t < Np + n_extra; t += virt) {
-            if (t < Np) f = f + pr::generic_prior_term(s_params, Np, d.priors, d.priors_switch, t, &st);
-            else f = f + pr::ms_global_extra_term(s_params, d.plength, d.extra, *u.dnu, t - Np);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) f = f + __shfl_down(f, off, 64);
-        f = __shfl(f, 0, 64);
-        total = (h == 0) ? f : total + f;
+    double f = 0;
+    for (int t = h * 64 + tid; t < Np + n_extra; t += virt) {
+        if (t < Np) f = f + pr::generic_prior_term(s_params, Np, d.priors, d.priors_switch, t, &st);
+        else f = f + pr::ms_global_extra_term(s_params, d.plength, d.extra, *u.dnu, t - Np);
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) f = f + __shfl_down(f, off, 64);
+    f = __shfl(f, 0, 64);
     if (st != TAMCMC_OK) *u.status = st;
     __syncthreads();
-    return *u.reject ? -INFINITY : total;
+    UPSTAMP(2);
+    *rejected = *u.reject;
+    return f;
 }
 
 // params (LDS) -> table rows of evaluation slot `slot` (+ noise row, range, counts).  `live` = the prior is finite
 // (model_def.cpp:472,476-480 skips the model otherwise).  u.S must hold shared_scalars_base (wg_log_prior did it).
 // empty_on_fail: a failed table leaves an EMPTY slot (nn = 0: the likelihood kernel skips it) instead of a placeholder noise row.
 __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, const UnpackLds &u, int slot, const TablePtrs &T,
-                                 bool live, bool vis_done = false, bool rows_done = false, bool empty_on_fail = false) {
+                                 bool live, bool vis_done = false, bool rows_done = false, bool empty_on_fail = false, long *pst = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x, per = d.per;
     mt::Shared *S = u.S;
+    UPSTAMP(0);
     if (live) {
         if (!vis_done) visibilities_stage(u, tid, WgSync());  // workgroup-uniform
+        UPSTAMP(1);
         if (rows_done) {  // rows already written with hv = H (wg_log_prior, early_rows): the visibilities are known now
             for (int e = tid; e < per * 7; e += nt) {
                 tamcmc_multiplet *r = &T.mults[(size_t)slot * per + e / 7];
@@ -272,7 +295,7 @@ __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, con
         } else
             for (int idx = tid; idx < per; idx += nt) {  // rows go straight to the likelihood kernel's table
                 const int st = mt::build_multiplet(d.model_id, *u.poly, s_params, *S, idx, d.x_first, d.x_last, d.Nx, d.step,
-                                                   &T.mults[(size_t)slot * per + idx]);
+                                                   &T.mults[(size_t)slot * per + idx], false, pst);
                 if (st) *u.status = st;
             }
         for (int i = tid; i < S->L.Nnoise; i += nt) T.noise[(size_t)slot * d.stride + i] = fabs(s_params[S->L.o_noise + i]);
@@ -280,6 +303,7 @@ __device__ inline void wg_unpack(const ModelDesc &d, const double *s_params, con
             wg_bg_tiles(d, s_params, S, slot, T, (nt > 64) ? 64 : 0, (nt > 64) ? nt - 64 : nt);  // beside the first wave's multiplet rows
     }
     __syncthreads();
+    UPSTAMP(2);
     if (tid == 0) {
         const bool ok = live && (*u.status == TAMCMC_OK);
         T.pairs[2 * slot] = slot * per;

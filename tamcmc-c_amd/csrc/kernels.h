@@ -23,7 +23,6 @@ struct LoglikeArgs {
 #endif
     int tile_rot = 0;     // tile dispatched first (launch order wraps around); any value in [0, ntiles) gives the same results
     int prio_b = -1;      // >= 0: evaluations prio_b and prio_b+1 are dispatched first (B >= 3); results do not depend on it
-    const int32_t *slot_map = nullptr;  // nullptr: evaluation b reads table slot b; else slot_map[b] & 0xffff (fused sampler step)
     const tamcmc_multiplet *mults;  // concatenated multiplet tables
     int per = 0, slot0 = 0;         // per > 0: evaluation b's table begins at row (slot0 + slot) * per (fixed-size slots, device-built tables)
     const int32_t *offsets;         // [2B] (begin,end) multiplet range per evaluation

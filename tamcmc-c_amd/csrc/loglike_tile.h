@@ -643,15 +643,17 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
 #undef PROBE_SKIP
 }
 
-// Tail hook of loglike_tile: called by every lane of every workgroup that owns a real tile, after its partial sums are in memory.
+// Hook of loglike_tile: which table slot evaluation b reads, and a tail called by every lane of every workgroup that owns a real tile
+// after its partial sums are written.
 struct NoTail {
     static constexpr bool coherent_partials = false;
+    __device__ __forceinline__ int slot(const LoglikeArgs &, int b) const { return b; }  // evaluation b reads table slot b
     __device__ __forceinline__ void operator()(int /*b*/, int /*tile*/, int /*slot*/) const {}
 };
 
 // Workgroup `id` of a launch over ntiles x B (tile, evaluation) pairs, XCD-aware: ids id, id+8, id+16, .. share an XCD (round-robin
 // dispatch), so all evaluations of one tile are placed on the XCD whose L2 holds that tile's x/y.
-// a.slot_map (fused sampler step): evaluation b reads the table in slot slot_map[b] (decided by the previous step on the device).
+// The hook names the table slot of evaluation b (fused sampler step: decided on the device from the previous launch's sums).
 template <int MODE, int WGS, int K, bool WRITE_MODEL, bool DELTA, class Tail>
 __device__ __forceinline__ void loglike_tile(const LoglikeArgs &a, const int id, TileLds<MODE, WGS> &S, const Tail &tail) {
     const int xcd = id & 7;
@@ -678,7 +680,7 @@ __device__ __forceinline__ void loglike_tile(const LoglikeArgs &a, const int id,
     if (tile >= a.ntiles) return;  // padding workgroup: leaves before any barrier
     tile += a.tile_rot;
     if (tile >= a.ntiles) tile -= a.ntiles;
-    const int sb = a.slot_map ? (a.slot_map[b] & 0xffff) : b;
+    const int sb = tail.slot(a, b);
     // everything the slot index leads to is requested at once (one memory round trip, not one per dependent step): the table's range,
     // the noise row's lengths; a.per > 0 (device-built tables in fixed-size slots): the range begins at (slot0 + sb) * per
     const int nn = a.nnoise[sb], nh = a.nharvey[sb];

@@ -112,7 +112,18 @@ TM_HD int ifact(int n) {  // function_rot.cpp:94-101 (n <= 6 on this path: table
     for (long i = 1; i <= n; i++) f *= i;
     return (int)f;
 }
-TM_HD double icombi(int n, int r) { return (double)(ifact(n) / ifact(n - r) / ifact(r)); }
+TM_HD double icombi(int n, int r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // n <= 6 on this path: Pascal's triangle packed one row per 64-bit constant (a byte per entry) -- the same integers as the
+    // factorial quotients below without three integer divisions per call
+    if (n >= 0 && n <= 6 && r >= 0 && r <= n) {
+        const unsigned long long row = n == 0 ? 0x01ull : n == 1 ? 0x0101ull : n == 2 ? 0x010201ull : n == 3 ? 0x01030301ull
+                                     : n == 4 ? 0x0104060401ull : n == 5 ? 0x01050a0a0501ull : 0x01060f140f0601ull;
+        return (double)(int)((row >> (8 * r)) & 0xff);
+    }
+#endif
+    return (double)(ifact(n) / ifact(n - r) / ifact(r));
+}
 // (-1)^n and x^n for small integer n.  Host: libm pow(), exactly what the reference calls.  Device: sign flip /
 // repeated multiplication (pow() on the GPU costs ~150 fp64 issue slots and serialises a lone lane for microseconds);
 // (-1)^n is exact either way, x^n agrees with pow() to <= 3 ulp for n <= 6.
@@ -121,6 +132,15 @@ TM_HD double pow_m1(int n) {
     return (n & 1) ? -1.0 : 1.0;
 #else
     return pow(-1.0, (double)n);
+#endif
+}
+// x^2.  Host: libm pow(x, 2.), what the reference calls (correctly rounded: the same value as x*x).  Device: the product -- pow() there is
+// ~150 fp64 issue slots, half a microsecond for a lone lane, and this sits in the per-m loop of every multiplet.
+TM_HD double pow_2(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x * x;
+#else
+    return pow(x, 2.);
 #endif
 }
 TM_HD double pow_int(double x, int n) {
@@ -163,6 +183,28 @@ TM_HD void amplitude_ratio(int l, double beta_deg, double *V) {
 // segment of the abscissa grid used by lin_interpol for xi: -1 none (NaN), else the left index of the segment
 TM_HD long lin_segment(const double *x, long n, double xi) {
     long seg = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (n >= 2 && n <= 16) {  // the same scan on a register copy of the grid: one batch of loads instead of two dependent ones per step
+        double g[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) g[k] = x[k < n ? k : n - 1];
+        const double xl = x[n - 1];
+        if (xi >= g[0] && xi <= xl) {
+            int i = 0;
+            bool go = true;
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                const bool adv = go && k < n - 2 && (xi < g[k] || xi > g[k + 1]);
+                i = adv ? k + 1 : i;
+                go = adv;
+            }
+            seg = i;
+        }
+        if (xi < g[0]) seg = 0;
+        if (xi > xl) seg = n - 2;
+        return seg;
+    }
+#endif
     if (xi >= x[0] && xi <= x[n - 1]) {
         long i = 0;
         while (i < n - 2 && (xi < x[i] || xi > x[i + 1])) ++i;
@@ -196,8 +238,13 @@ TM_HD void linfit_index(const double *y, long n, double out[2]) {
 }
 TM_HD double eta0_from_dnu(double dnu) {
     const double G = 6.667e-8, Dnu_sun = 135.1, R_sun = 6.96342e5, M_sun = 1.98855e30;
-    const double rho_sun = M_sun * 1e3 / (4 * 3.14159265358979323846 * pow(R_sun * 1e5, 3) / 3);
-    const double rho = pow(dnu / Dnu_sun, 2.) * rho_sun;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double R3 = 0x1.0a5c08c31239dp+108;  // pow(R_sun * 1e5, 3) as libm returns it
+#else
+    const double R3 = pow(R_sun * 1e5, 3);
+#endif
+    const double rho_sun = M_sun * 1e3 / (4 * 3.14159265358979323846 * R3 / 3);
+    const double rho = pow_2(dnu / Dnu_sun) * rho_sun;
     return 3. * 3.14159265358979323846 / (rho * G);
 }
 TM_HD double eta0_fct(const double *fl0, long n) {
@@ -240,12 +287,12 @@ TM_HD double nu_nlm_aj(const PolyTab &T, double fc, const double a[7], double et
     xreal acc = fc + a[1] * T.P[1][l][m + 3] + a[2] * T.P[2][l][m + 3] + a[3] * T.P[3][l][m + 3] + a[4] * T.P[4][l][m + 3] +
                 a[5] * T.P[5][l][m + 3] + a[6] * T.P[6][l][m + 3];
     double nu = (double)acc;
-    if (eta0 > 0) nu = nu + fc * eta0 * T.Q[l][m + 3] * pow(a[1] * 1e-6, 2);
+    if (eta0 > 0) nu = nu + fc * eta0 * T.Q[l][m + 3] * pow_2(a[1] * 1e-6);
     return nu;
 }
 // build_lorentzian.cpp:145
 TM_HD double nu_nlm_a1etaa3(const PolyTab &T, double fc, double f_s, double eta0, double a3, int l, int m) {
-    const double t = fc * (1. + eta0 * pow(f_s * 1e-6, 2) * T.Q[l][m + 3]) + m * f_s;
+    const double t = fc * (1. + eta0 * pow_2(f_s * 1e-6) * T.Q[l][m + 3]) + m * f_s;
     const xreal acc = t + T.P[3][l][m + 3] * a3;
     return (double)acc;
 }
@@ -315,7 +362,7 @@ TM_HD void shared_scalars_base(int model_id, const double *p, const int32_t *pl,
         double inc = atan(p[L.o_split + 4] / p[L.o_split + 3]);
         inc = (double)(inc * 180. / pi);
         S.inc = inc;
-        S.a1 = pow(p[L.o_split + 3], 2) + pow(p[L.o_split + 4], 2);
+        S.a1 = pow_2(p[L.o_split + 3]) + pow_2(p[L.o_split + 4]);
         for (int l = 1; l <= 3; l++)
             if (L.Nfl[l] >= 1) S.need_ratio[l] = 1;
         S.eta0 = p[L.o_split + 1];
@@ -355,9 +402,15 @@ TM_HD xreal xabs(xreal v) { return v < 0 ? -v : v; }
 // aj: l-major (all l=0, then l=1, ...) models.cpp:1288-1376; Classic: n-major (l=0..lmax per order) :2026-2085;
 // local: l-major :3096-3159.
 // defer_ratio: leave hv[m] = H (the caller multiplies by the m-visibilities once they are known: same product, same bits)
+#if defined(TAMCMC_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+#define BMSTAMP(k) do { if (pst && index == 20) pst[k] = (long)wall_clock64(); } while (0)
+#else
+#define BMSTAMP(k)
+#endif
 TM_HD int build_multiplet(int model_id, const PolyTab &T, const double *p, const Shared &S, int index, double x_first,
-                          double x_last, int64_t Nx, double step, tamcmc_multiplet *r, bool defer_ratio = false) {
+                          double x_last, int64_t Nx, double step, tamcmc_multiplet *r, bool defer_ratio = false, long *pst = nullptr) {
     const Layout &L = S.L;
+    BMSTAMP(4);
     int l = 0, n = 0;
     if (model_id == TAMCMC_MODEL_MS_GLOBAL_A1ETAA3_CLASSIC) {
         const int per_n = 1 + (L.lmax < 3 ? (L.lmax > 0 ? L.lmax : 0) : 3);
@@ -417,20 +470,31 @@ TM_HD int build_multiplet(int model_id, const PolyTab &T, const double *p, const
         f_s = S.a1;
     }
     int i0 = 0, i1 = 0;
+    BMSTAMP(5);
     const int st = set_imin_imax(x_first, x_last, Nx, l, f, W, f_s, S.trunc_c, step, &i0, &i1);
+    BMSTAMP(6);
     if (st) return st;
     r->l = l; r->i0 = i0; r->i1 = i1; r->flags = 0;
     r->fc = f; r->gamma = W; r->asym = S.asym;
-    for (int k = 0; k < 7; k++) { r->nu[k] = 0.0; r->hv[k] = 0.0; }
-    for (int m = -l; m <= l; m++) {
-        double nu = f;
-        if (l != 0) {
-            if (model_id == TAMCMC_MODEL_MS_GLOBAL_AJ) nu = nu_nlm_aj(T, f, a, eta0, l, m);
-            else nu = nu_nlm_a1etaa3(T, f, f_s, eta0, S.a3, l, m);
+    // the 2l+1 components, unused entries zero (a constant trip count: the table reads of all seven go out together)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 7; k++) {
+        const int m = k - l;
+        double nu = 0.0, hv = 0.0;
+        if (k <= 2 * l) {
+            nu = f;
+            if (l != 0) {
+                if (model_id == TAMCMC_MODEL_MS_GLOBAL_AJ) nu = nu_nlm_aj(T, f, a, eta0, l, m);
+                else nu = nu_nlm_a1etaa3(T, f, f_s, eta0, S.a3, l, m);
+            }
+            hv = defer_ratio ? H : H * S.ratios[l][k];
         }
-        r->nu[m + l] = nu;
-        r->hv[m + l] = defer_ratio ? H : H * S.ratios[l][m + l];
+        r->nu[k] = nu;
+        r->hv[k] = hv;
     }
+    BMSTAMP(7);
     return TAMCMC_OK;
 }
 

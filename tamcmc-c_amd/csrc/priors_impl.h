@@ -131,7 +131,31 @@ TM_HD xreal ms_global_constraints(const double *params, const int *pl, const int
     int n_aj = 0;
     if (model_index == 9)
         for (int el = 1; el < lmax + 1 && el < 4; el++) n_aj += 5 * Nfl[el];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the same checks dealt out by (degree, order) pair, the five a_j of a pair on one lane: no integer division to find a check's
+    // indices, a1 formed once per pair (every check is independent: any one failing rejects)
+    for (int t = t0; t < n_vis; t += stride)
+        if (params[Nmax + t] < 0) return neg_inf();
+    if (n_aj > 0) {
+        const int npairs = n_aj / 5;
+        for (int pr_ = t0; pr_ < npairs; pr_ += stride) {
+            int n = pr_, el = 1, i0 = Nfl[0];
+            while (el < 3 && n >= Nfl[el]) { n -= Nfl[el]; i0 += Nfl[el]; el++; }
+            const double fl = params[Nmax + lmax + i0 + n];
+            const double a1 = params[Nmax + lmax + Nf] + params[Nmax + lmax + Nf + 1] * (fl * 1e-3);
+            bool bad = a1 < 0;
+#pragma unroll 1
+            for (int j = 1; j <= 5; j++) {
+                const double aj = params[Nmax + lmax + Nf + 2 * j] + params[Nmax + lmax + Nf + 2 * j + 1] * (fl * 1e-3);
+                bad = bad || (fabs(aj / a1) >= ajova1_limit[j]);
+            }
+            if (bad) return neg_inf();
+        }
+    }
+    for (int t = n_vis + n_aj; t < n_vis + n_aj; t += stride) {
+#else
     for (int t = t0; t < n_vis + n_aj; t += stride) {
+#endif
         if (t < n_vis) {  // priors_calc.cpp:63-68
             if (params[Nmax + t] < 0) return neg_inf();
             continue;
@@ -207,7 +231,7 @@ TM_HD xreal local_constraints(const double *params, const int *pl, const int *sw
     if (params[o] != 0) {  // an a1 is fitted directly (priors_calc.cpp:541-546)
         if (fabs(params[o + 2] / params[o]) >= a3ova1_limit) return neg_inf();
     } else if ((params[o + 3] != 0) && (params[o + 4] != 0)) {  // sqrt(a1) cos i, sqrt(a1) sin i (:547-554)
-        if (fabs(params[o + 2] / (pow(params[o + 3], 2) + pow(params[o + 4], 2))) >= a3ova1_limit) return neg_inf();
+        if (fabs(params[o + 2] / (mt::pow_2(params[o + 3]) + mt::pow_2(params[o + 4]))) >= a3ova1_limit) return neg_inf();
     }
     const int oi = o + Nsplit + Nwidth + Nnoise;  // inclination slot (:561-564)
     if ((sw[oi] != 0) && (params[oi] < 0)) return neg_inf();
