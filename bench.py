@@ -361,6 +361,8 @@ def main():
         evals_per_launch = k_evals / max(k_launches, 1)
         k_s = k_ms * 1e-3 / max(k_launches, 1)
         alg_bytes = 16.0 * a.nx * evals_per_launch          # B_eval = 16*Nx bytes per evaluation
+        if k_launches <= 0 or k_s <= 0:
+            raise SystemExit("bench.py: no launch of the dominant kernel was timed inside the timed region (no roofline without a live measurement)")
         achieved = alg_bytes / k_s / 1e9                     # one launch of the dominant kernel
         agg = value / world * a.chains * 16.0 * a.nx / 1e9   # the whole timed region
         launches_per_iter = k_launches / max(a.steps, 1)
@@ -383,8 +385,8 @@ def main():
                                    f"{len(mults)} multiplets, {a.chains} tempered chains (lambda={lam}), one star per GPU",
                        "sampler": "adaptive random-walk MH + parallel tempering (use_drift=0, the reference's sampler)"
                        if a.sampler == "mh" else "Langevin drift, forward-difference gradient (use_drift=1)",
-                       "engine": (("device-resident iteration, fused launches (likelihood tiles + settle in their tail + next iteration's candidates), one per "
-                                   "chain group and iteration on two streams"
+                       "engine": (("device-resident iteration, fused launches (likelihood tiles of iteration i, each deciding iteration i-1 for its chain first + commit "
+                                   "workgroups + iteration i+1's candidates), one per chain group and iteration on two streams"
                                    if fused else "device-resident iteration, lockstep kernels (k_iterate, k_loglike)")
                                   if (a.engine == "device" and a.sampler == "mh") else "host-driven loop"),
                        "phases": f"set-up: {SETUP_ITERS} burn-in + learning iterations with adaptation in {SETUP_LEARN}, the last {min(max(a.steps, a.warmup, 1), 256)} of them recorded like the timed ones (untimed); then {a.warmup} warm-up + "

@@ -2035,7 +2035,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         // the groups: see straddles() below.  (Same chains bit for bit: the launches' contents are the same.)
         const int first1 = f.xsplit;
         hipStream_t s1 = I.gst[1];
-        long n_split = 0;
+        long n_split = 0, next_sample = len >= 97 ? 48 : len / 2;
         bool s1_ahead = false, s1_must_wait = st_has_work;  // s1 holds launches st has not waited for / s1 has not seen st's latest launches
         auto swap_pair_of = [&](long it) -> int {
             if (!(a.C >= 2 && a.dN_mixing > 0 && (it % a.dN_mixing == 0) && it != 0)) return -1;
@@ -2095,11 +2095,13 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
                 }
                 int rc = launch_group(0, first1, A, i, settled, st);
                 if (rc) return rc;
-                const bool sample = timed && g_used < I.n_gev && (len >= 97 ? ((i - ia) % 97 == 48) : (i - ia == len / 2));
+                // (sampled launches: every 97th iteration, or the middle one of a short stretch -- the first two-group iteration at or
+                // after it: a joint iteration there must not leave a short call without a measured launch)
+                const bool sample = timed && g_used < I.n_gev && (i - ia) >= next_sample;
                 rc = sample ? launch_group(first1, a.C - first1, A, i, settled, s1, I.gev[g_used][0], I.gev[g_used][1])
                             : launch_group(first1, a.C - first1, A, i, settled, s1);
                 if (rc) return rc;
-                if (sample) g_used++;
+                if (sample) { g_used++; next_sample += 97; }
                 s1_ahead = true;
                 n_split++;
             } else {

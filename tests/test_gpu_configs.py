@@ -199,3 +199,18 @@ def test_two_ranks_run_the_bench_path_and_match_solo_runs(pkg, synth, tmp_path):
         ref, _ = s.run(steps, stats=True)
         assert got.shape == ref.shape and np.array_equal(got, ref), rank
         s.close(); ctx.close()
+
+
+@pytest.mark.parametrize("steps,warm", [(20, 5), (7, 0), (100, 3)])
+def test_the_drivers_bench_command_prints_its_line(steps, warm):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` is what the driver records; short windows must still carry a live measurement of
+    the dominant kernel (a window whose middle iteration is a joint launch of both chain groups once left none: round 3)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm), "--headline-only"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["steps"] == steps and d["warmup"] == warm and d["n_gpus"] == 1
+    k = d["roofline"]["kernel"]
+    assert k["us_per_launch"] > 1.0 and 0 < k["frac"] < 1 and 0 < d["roofline"]["frac"] < 1
+    assert d["value"] == pytest.approx(steps / (d["ms_per_step"] * 1e-3 * steps))
+    assert d["end_to_end_check"]["max_rel_err_logL_final_states_vs_STRICT"] <= 1e-11
