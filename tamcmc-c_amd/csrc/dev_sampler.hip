@@ -1787,8 +1787,24 @@ struct RunningCall {
     ~RunningCall() { g_running_calls.fetch_sub(1, std::memory_order_relaxed); }
 };
 
+// TAMCMC_CALL_TIMELINE=1: host-side stamps of every run() call on stderr (entry -> first launch -> all launches enqueued -> streams idle)
+static const bool g_call_timeline = getenv("TAMCMC_CALL_TIMELINE") != nullptr;
+struct CallTimeline {
+    std::chrono::steady_clock::time_point t[5];
+    int n = 0;
+    void mark() { if (g_call_timeline && n < 5) t[n++] = std::chrono::steady_clock::now(); }
+    ~CallTimeline() {
+        if (!g_call_timeline || n < 2) return;
+        fprintf(stderr, "run() timeline (us):");
+        for (int k = 1; k < n; k++) fprintf(stderr, " %.1f", std::chrono::duration<double, std::micro>(t[k] - t[k - 1]).count());
+        fprintf(stderr, "\n");
+    }
+};
+
 int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, double *stats) {
     RunningCall running_call;
+    CallTimeline tl;
+    tl.mark();
     Impl &I = *impl;
     tamcmc_hip_ctx *c = I.ctx;
     DevSamplerArgs &a = I.a;
@@ -1868,6 +1884,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
         l.per = a.desc.per; l.slot0 = 0;
     }
 
+    tl.mark();  // (set-up of the call done: buffers, argument blocks)
     int used_ev = 0;
     std::vector<std::pair<int, long>> fused_ev;  // (event pair, launches it brackets) of the fused stretches of this call
     // fused step with two chain groups: the launches of an iteration overlap, so the stretch's elapsed time is not a launch duration;
@@ -2170,6 +2187,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     }
     I.parity = P;
     DCHK(hipGetLastError());
+    tl.mark();  // (every launch enqueued)
     if (s1_open && ((samples && !zc_smp) || (stats && !zc_st))) {  // (the copies below read what the second group's launches write)
         DCHK(hipEventRecord(I.ev_join[1], I.gst[1]));
         DCHK(hipStreamWaitEvent(st, I.ev_join[1], 0));
@@ -2180,6 +2198,7 @@ int DevSampler::run(long it0, long n_iter, const char *learn, double *samples, d
     const bool poll = g_running_calls.load(std::memory_order_relaxed) == 1;
     if (s1_open) DCHK(Impl::wait_stream(I.gst[1], poll));
     DCHK(Impl::wait_stream(st, poll));
+    tl.mark();  // (streams idle)
     for (const auto &e : fused_ev) {
         float ms = 0;
         DCHK(hipEventElapsedTime(&ms, I.ev[e.first][0], I.ev[e.first][1]));

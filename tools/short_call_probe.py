@@ -1,5 +1,5 @@
 """What a short run() call costs on the headline star (the driver's bench window is 20 iterations after 5 warm-up ones):
-wall time of calls of n iterations, against n x the steady-state iteration time.  python tools/short_call_probe.py [n] [calls]"""
+wall time of calls of n iterations, against n x the steady-state iteration time.  python tools/short_call_probe.py [n] [calls] [timing 0/1]"""
 import os
 import sys
 import time
@@ -15,8 +15,9 @@ from tamcmc_c_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+timing = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True   # sampled launches bracketed by events (what bench.py runs with)
 star = synth.make_c3_star()
-ctx = pkg.HipContext(0, precision=pkg.PRECISION_STRICT, timing=True)
+ctx = pkg.HipContext(0, precision=pkg.PRECISION_STRICT, timing=timing)
 ctx.set_spectrum(star.x, np.ones_like(star.x))
 _, m0, _ = ctx.loglike_params_batch(star.model_id, star.params, star.plength, want_model=True)
 star.set_spectrum_from_model(m0[0], seed=20240301)
