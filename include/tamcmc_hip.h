@@ -178,6 +178,10 @@ int tamcmc_hip_reset_kernel_stats(tamcmc_hip_ctx *ctx);
  * the delta evaluations and the number of those evaluations -- the bytes such a launch really touches are 24 B per affected bin
  * (x, y, base model row), not 16 B x Nx per evaluation. */
 int tamcmc_hip_get_fd_stats(tamcmc_hip_ctx *ctx, int64_t *affected_bins, int64_t *delta_evaluations);
+/* ... and how many of those delta evaluations were "full tables": a perturbation that moves most multiplets (a splitting coefficient,
+ * the asymmetry) is evaluated as the whole perturbed table minus the stored base model row instead of +new / -old row pairs
+ * (FAST arithmetic only; same tolerance as the pair tables: the unchanged rows cancel exactly). */
+int tamcmc_hip_get_fd_full_tables(tamcmc_hip_ctx *ctx, int64_t *full_table_evaluations);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ ABI = [
     ("tamcmc_hip_get_kernel_stats", C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("tamcmc_hip_reset_kernel_stats", C.c_int, [_vp]),
     ("tamcmc_hip_get_fd_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("tamcmc_hip_get_fd_full_tables", C.c_int, [_vp, C.POINTER(C.c_int64)]),
 ]
 
 _lib = None
@@ -257,6 +258,12 @@ class HipContext:
         b, e = C.c_int64(0), C.c_int64(0)
         self._chk(self._L.tamcmc_hip_get_fd_stats(self._h, C.byref(b), C.byref(e)))
         return b.value, e.value
+
+    def fd_full_tables(self):
+        """Delta evaluations since the last reset that were evaluated as whole perturbed tables (timing on)."""
+        n = C.c_int64(0)
+        self._chk(self._L.tamcmc_hip_get_fd_full_tables(self._h, C.byref(n)))
+        return n.value
 
     def reset_kernel_stats(self):
         self._chk(self._L.tamcmc_hip_reset_kernel_stats(self._h))

@@ -370,6 +370,12 @@ int tamcmc_hip_get_fd_stats(tamcmc_hip_ctx *c, int64_t *affected_bins, int64_t *
     return TAMCMC_OK;
 }
 
+int tamcmc_hip_get_fd_full_tables(tamcmc_hip_ctx *c, int64_t *full_table_evaluations) {
+    if (!c) return TAMCMC_ERR_BAD_ARG;
+    if (full_table_evaluations) *full_table_evaluations = c->fd_full_evals;
+    return TAMCMC_OK;
+}
+
 int tamcmc_hip_reset_kernel_stats(tamcmc_hip_ctx *c) {
     if (!c) return TAMCMC_ERR_BAD_ARG;
     c->kernel_ms = 0;
@@ -377,6 +383,7 @@ int tamcmc_hip_reset_kernel_stats(tamcmc_hip_ctx *c) {
     c->evals = 0;
     c->fd_bins = 0;
     c->fd_delta_evals = 0;
+    c->fd_full_evals = 0;
     return TAMCMC_OK;
 }
 

@@ -92,6 +92,7 @@ struct tamcmc_hip_ctx {
     // stats
     double kernel_ms = 0;
     int64_t launches = 0, evals = 0;
+    int64_t fd_full_evals = 0;                // ... of which "full table" evaluations (fd_batch.hip)
     int64_t fd_bins = 0, fd_delta_evals = 0;  // windowed finite differences (timing on): bins inside the affected ranges, delta evaluations
 };
 

@@ -2255,7 +2255,7 @@ int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *sampl
             DCHK(hipStreamSynchronize(st));
             DCHK(I.fd_part.reserve(nb.nS * (size_t)nb.ntiles * 2));
             DCHK(I.fd_S.reserve(nb.nS));
-            if (nb.windowed) DCHK(I.fd_model.reserve(2 * C * (size_t)c->Nx));  // two planes: 1/M0, y/M0 of the base points
+            if (nb.windowed) DCHK(I.fd_model.reserve(3 * C * (size_t)c->Nx));  // three planes: 1/M0, y/M0, M0 of the base points
             if (c->precision == TAMCMC_PRECISION_FAST) DCHK(I.fd_bg.reserve((size_t)(nb.windowed ? a.C : nb.B) * nb.ntiles * 8));
             I.grad_valid = false;
         }

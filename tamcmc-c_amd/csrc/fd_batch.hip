@@ -43,6 +43,7 @@ struct FdArgs {
     int *d_range, *d_flags, *d_row;
     double *d_noise_old;
     TablePtrs Bs;          // base launch (C evaluations): ranges / counts / noise rows indexed by chain
+    int full_tables;       // 1: "full table" delta evaluations allowed (the base launch's background series are at hand: FAST arithmetic)
 };
 
 __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
@@ -112,55 +113,73 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
         return;
     }
     // ---- delta table: the multiplets whose row differs from the base row, +new / -old, and the affected bin range ----
-    if (tid == 0) { s_lo = a.desc.Nx; s_hi = 0; s_nchg = 0; s_noise_chg = 0; }
+    __shared__ int s_namp, s_nshape;
+    if (tid == 0) { s_lo = a.desc.Nx; s_hi = 0; s_nchg = 0; s_noise_chg = 0; s_namp = 0; s_nshape = 0; }
     __syncthreads();
     const bool ok = (a.status[slot] == TAMCMC_OK) && (s_base_status == TAMCMC_OK);
     tamcmc_multiplet *drows = a.D.mults + (size_t)slot * 2 * per;
-    for (int j0 = 0; j0 < per; j0 += FB) {
-        const int jdx = j0 + tid;
-        bool chg = false;
-        if (ok && jdx < per) {
-            const unsigned long long *pn = (const unsigned long long *)&a.T.mults[(size_t)slot * per + jdx];
-            const unsigned long long *po = (const unsigned long long *)&a.T.mults[(size_t)(B + slot) * per + jdx];
-            for (int w = 0; w < (int)(sizeof(tamcmc_multiplet) / 8); w++) chg = chg || (pn[w] != po[w]);
-        }
-        if (chg) {
-            const tamcmc_multiplet &rn = a.T.mults[(size_t)slot * per + jdx];
-            tamcmc_multiplet ro = a.T.mults[(size_t)(B + slot) * per + jdx];
-            // a parameter that only rescales heights (inclination, visibilities, heights) leaves frequencies, width, asymmetry and
-            // window untouched: +new and -old are then ONE row with the height differences (half the work of the pair)
-            bool amp_only = (rn.l == ro.l) && (rn.i0 == ro.i0) && (rn.i1 == ro.i1) && (rn.fc == ro.fc) && (rn.gamma == ro.gamma) && (rn.asym == ro.asym);
-            for (int m = 0; m < 7; m++) amp_only = amp_only && (rn.nu[m] == ro.nu[m]);
-            const int pos = atomicAdd(&s_nchg, amp_only ? 1 : 2);   // order of the changed rows is irrelevant (a sum)
-            if (amp_only) {
-                for (int m = 0; m < 7; m++) ro.hv[m] = rn.hv[m] - ro.hv[m];
-                drows[pos] = ro;
-            } else {
-                for (int m = 0; m < 7; m++) ro.hv[m] = -ro.hv[m];
-                drows[pos] = rn;
-                drows[pos + 1] = ro;
-            }
-            atomicMin(&s_lo, min(rn.i0, ro.i0));
-            atomicMax(&s_hi, max(rn.i1, ro.i1));
-        }
-    }
     for (int i = tid; i < stride; i += FB) {
         const double vn = a.T.noise[(size_t)slot * stride + i], vo = a.T.noise[(size_t)(B + slot) * stride + i];
         a.D.noise[(size_t)slot * stride + i] = vn;
         a.d_noise_old[(size_t)slot * stride + i] = vo;
         if (ok && i < a.T.nn[slot] && vn != vo) s_noise_chg = 1;
     }
+    // how row jdx changed: 0 not at all, 1 heights only (a parameter that only rescales heights -- inclination, visibilities, heights --
+    // leaves frequencies, width, asymmetry and window untouched: +new and -old are then ONE row with the height differences), 2 otherwise
+    auto change_of = [&](int jdx) -> int {
+        if (!ok || jdx >= per) return 0;
+        const unsigned long long *pn = (const unsigned long long *)&a.T.mults[(size_t)slot * per + jdx];
+        const unsigned long long *po = (const unsigned long long *)&a.T.mults[(size_t)(B + slot) * per + jdx];
+        bool chg = false;
+        for (int w = 0; w < (int)(sizeof(tamcmc_multiplet) / 8); w++) chg = chg || (pn[w] != po[w]);
+        if (!chg) return 0;
+        const tamcmc_multiplet &rn = a.T.mults[(size_t)slot * per + jdx], &ro = a.T.mults[(size_t)(B + slot) * per + jdx];
+        bool amp_only = (rn.l == ro.l) && (rn.i0 == ro.i0) && (rn.i1 == ro.i1) && (rn.fc == ro.fc) && (rn.gamma == ro.gamma) && (rn.asym == ro.asym);
+        for (int m = 0; m < 7; m++) amp_only = amp_only && (rn.nu[m] == ro.nu[m]);
+        return amp_only ? 1 : 2;
+    };
+    for (int j0 = 0; j0 < per; j0 += FB) {
+        const int k = change_of(j0 + tid);
+        if (k == 1) atomicAdd(&s_namp, 1);
+        else if (k == 2) atomicAdd(&s_nshape, 1);
+    }
+    __syncthreads();
+    // "full table": the pairs would be longer than the perturbed point's whole table (a parameter that moves most multiplets: a splitting
+    // coefficient, the asymmetry) -- the delta launch then evaluates that table and subtracts the base model row (loglike_tile.h)
+    const bool full = ok && !s_noise_chg && a.full_tables && (s_namp + 2 * s_nshape > per);
+    if (full) {
+        for (int jdx = tid; jdx < per; jdx += FB) drows[jdx] = a.T.mults[(size_t)slot * per + jdx];
+    } else
+        for (int j0 = 0; j0 < per; j0 += FB) {
+            const int jdx = j0 + tid, k = change_of(jdx);
+            if (k) {
+                const tamcmc_multiplet &rn = a.T.mults[(size_t)slot * per + jdx];
+                tamcmc_multiplet ro = a.T.mults[(size_t)(B + slot) * per + jdx];
+                const int pos = atomicAdd(&s_nchg, k);   // order of the changed rows is irrelevant (a sum)
+                if (k == 1) {
+                    for (int m = 0; m < 7; m++) ro.hv[m] = rn.hv[m] - ro.hv[m];
+                    drows[pos] = ro;
+                } else {
+                    for (int m = 0; m < 7; m++) ro.hv[m] = -ro.hv[m];
+                    drows[pos] = rn;
+                    drows[pos + 1] = ro;
+                }
+                atomicMin(&s_lo, min(rn.i0, ro.i0));
+                atomicMax(&s_hi, max(rn.i1, ro.i1));
+            }
+        }
     __syncthreads();
     if (tid == 0) {
-        const int n = s_nchg;
+        const int n = full ? per : s_nchg;
+        const bool all_bins = s_noise_chg || full;
         a.D.pairs[2 * slot] = slot * 2 * per;
-        a.D.pairs[2 * slot + 1] = slot * 2 * per + n;  // n = rows written (one or two per changed multiplet)
+        a.D.pairs[2 * slot + 1] = slot * 2 * per + n;  // n = rows written (one or two per changed multiplet, or the whole table)
         a.D.nh[slot] = a.T.nh[slot];
         a.D.nn[slot] = a.T.nn[slot];
-        a.d_flags[slot] = s_noise_chg;
+        a.d_flags[slot] = s_noise_chg | (full ? 2 : 0);
         a.d_row[slot] = c;
-        a.d_range[2 * slot] = s_noise_chg ? 0 : (n ? s_lo : 0);
-        a.d_range[2 * slot + 1] = s_noise_chg ? a.desc.Nx : (n ? s_hi : 0);
+        a.d_range[2 * slot] = all_bins ? 0 : (n ? s_lo : 0);
+        a.d_range[2 * slot + 1] = all_bins ? a.desc.Nx : (n ? s_hi : 0);
     }
 }
 
@@ -248,6 +267,7 @@ int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_param
     fa.idx = (const int *)(db + o_idx); fa.h = (const double *)(db + o_h);
     fa.logPr_plus = (double *)(db + o_lpp); fa.logPr_minus = (double *)(db + o_lpm); fa.status = (int *)(db + o_st);
     fa.windowed = windowed ? 1 : 0;
+    fa.full_tables = (windowed && c->precision == TAMCMC_PRECISION_FAST && bgbuf) ? 1 : 0;
     fa.D = fa.T; fa.Bs = fa.T;
     fa.d_range = nullptr; fa.d_flags = nullptr; fa.d_row = nullptr; fa.d_noise_old = nullptr;
     if (windowed) {
@@ -280,7 +300,7 @@ int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_param
         // (1) the C base points: full evaluation, model rows kept
         a.B = C;
         a.mults = fa.T.mults; a.offsets = fa.Bs.pairs; a.noise = fa.Bs.noise; a.nharvey = fa.Bs.nh; a.nnoise = fa.Bs.nn;
-        a.partials = part; a.model = model; a.fd_rows = model; a.fd_plane = (size_t)C * Nx;  // (1/M0 and y/M0 planes instead of the rows)
+        a.partials = part; a.model = model; a.fd_rows = model; a.fd_plane = (size_t)C * Nx;  // (1/M0, y/M0 and M0 planes instead of the rows)
         if (c->precision == TAMCMC_PRECISION_FAST) {
             HIPCHK(c, launch_bg_poly(a, c->wgs, c->K, bgbuf, st));
             a.bg_poly = bgbuf;
@@ -289,7 +309,8 @@ int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_param
         HIPCHK(c, launch_finalize(part, C, ntiles, S, st));
         // (2) the C*Nvars perturbed points: log-likelihood DIFFERENCES from the delta tables
         LoglikeArgs d = a;
-        d.B = B; d.model = nullptr; d.fd_rows = nullptr; d.bg_poly = nullptr;
+        d.B = B; d.model = nullptr; d.fd_rows = nullptr;
+        d.bg_poly = fa.full_tables ? bgbuf : nullptr;  // (rows by base point: read by the "full table" evaluations only)
         d.mults = fa.D.mults; d.offsets = fa.D.pairs; d.noise = fa.D.noise; d.nharvey = fa.D.nh; d.nnoise = fa.D.nn;
         d.partials = part + (size_t)C * ntiles * 2;
         d.d_range = fa.d_range; d.d_flags = fa.d_flags; d.d_row = fa.d_row; d.d_noise_old = fa.d_noise_old; d.model0 = model;
@@ -354,7 +375,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     HIPCHK(c, c->d_part.reserve(nS * fb.ntiles * 2));
     HIPCHK(c, c->d_S.reserve(nS));
     HIPCHK(c, c->h_S.reserve(nS));
-    if (windowed) HIPCHK(c, c->d_model.reserve(2 * (size_t)C * c->Nx));  // two planes: 1/M0, y/M0
+    if (windowed) HIPCHK(c, c->d_model.reserve(3 * (size_t)C * c->Nx));  // three planes: 1/M0, y/M0, M0
     if (c->precision == TAMCMC_PRECISION_FAST) HIPCHK(c, c->d_bg.reserve((size_t)(windowed ? C : B) * fb.ntiles * 8));
     rc = fb.enqueue(c, db, nullptr, c->d_part.p, c->d_S.p, c->d_model.p, c->d_bg.p, c->timing ? c->ev0 : nullptr, c->timing ? c->ev1 : nullptr);
     if (rc) return rc;
@@ -372,6 +393,9 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
             HIPCHK(c, hipMemcpy(rg.data(), db + o_drange, rg.size() * sizeof(int), hipMemcpyDeviceToHost));
             for (int s = 0; s < B; s++) c->fd_bins += rg[2 * (size_t)s + 1] - rg[2 * (size_t)s];
             c->fd_delta_evals += B;
+            std::vector<int> fl((size_t)B);
+            HIPCHK(c, hipMemcpy(fl.data(), db + fb.o_dflags, fl.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int s = 0; s < B; s++) c->fd_full_evals += (fl[(size_t)s] & 2) ? 1 : 0;
         }
     }
     const double *lpp = (const double *)(hb + o_lpp), *lpm = (const double *)(hb + o_lpm);

@@ -39,10 +39,11 @@ struct LoglikeArgs {
     // new rows with +H*V and old rows with -H*V, so the kernel accumulates dM = M(theta + h e_k) - M(theta); the partial
     // sums are those of the log-likelihood DIFFERENCE against the base model row, over the affected bins only.
     const int32_t *d_range = nullptr;     // [2B] affected bin range [lo, hi) of evaluation b
-    const int32_t *d_flags = nullptr;     // [B]  bit 0: the noise parameters changed (background difference on every bin)
+    const int32_t *d_flags = nullptr;     // [B]  bit 0: the noise parameters changed (background difference on every bin); bit 1: the table
+                                          //      holds EVERY row of the perturbed point (+H*V): dM = M - M0 against model0's third plane
     const double *d_noise_old = nullptr;  // [B x noise_stride] |noise params| of the base point
     const int32_t *d_row = nullptr;       // [B]  row of model0 holding the base point of evaluation b
-    // base point of the finite differences, two planes of [rows x Nx], fd_plane doubles apart: 1/M0 and y/M0.  Written by the base launch
+    // base point of the finite differences, three planes of [rows x Nx], fd_plane doubles apart: 1/M0, y/M0 and M0.  Written by the base launch
     // (WRITE_MODEL with fd_rows set, instead of the model rows), read by the DELTA launch (model0).
     const double *model0 = nullptr;
     double *fd_rows = nullptr;

@@ -267,11 +267,18 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     }
 
     tamcmc_multiplet g;
+    // DELTA, bit 1 of the evaluation's flags ("full table"): a perturbation that moves most multiplets (a splitting coefficient, the
+    // asymmetry) is cheaper as the WHOLE perturbed model minus the base model row M0 (third plane of model0) than as +new / -old row
+    // pairs -- per rows instead of up to 2 per.  The table then holds every row of the perturbed point, the background is the base
+    // point's (the noise parameters did not change: its prebuilt series, a.bg_poly rows by base point), and dM = M - M0 per bin.  The
+    // unchanged rows and the background are summed by the same code in the same order as in the base launch: they cancel exactly.
+    const bool fullnew = DELTA && (a.d_flags[b] & 2);
+    const bool dsub = DELTA && !fullnew;  // the evaluation carries -old rows / the old noise row: differences are formed term by term
     // prebuilt background series of this (evaluation, tile), one coefficient per lane: it stays in those lanes' registers and enters the
     // tile polynomial where the far-field sums are closed (no wait for it here, no trip through LDS)
-    const bool bg_prebuilt = FARFIELD && !DELTA && a.bg_poly;
+    const bool bg_prebuilt = FARFIELD && a.bg_poly && (!DELTA || fullnew);
     double bg_pre = 0.0;
-    if (bg_prebuilt && tid < NH) bg_pre = a.bg_poly[((size_t)sb * a.ntiles + tile) * NH + tid];
+    if (bg_prebuilt && tid < NH) bg_pre = a.bg_poly[((size_t)(DELTA ? a.d_row[b] : sb) * a.ntiles + tile) * NH + tid];
     double xv[K], yv[K], acc[K];
     int bin[K];
 #pragma unroll
@@ -284,7 +291,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
 
     const double *nz = a.noise + (size_t)sb * a.noise_stride;
     // DELTA: background difference only when the noise parameters changed (same Harvey count on both sides)
-    const bool bg = !DELTA || (a.d_flags[b] & 1);
+    const bool bg = !DELTA || fullnew || (a.d_flags[b] & 1);
     const double *nzo = DELTA ? a.d_noise_old + (size_t)b * a.noise_stride : nz;
     // tile geometry for the far field: centre and half-width of the nominal tile on the regular grid
     const double h = 0.5 * (double)TILE * a.step;
@@ -295,7 +302,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     if (FAST && bg && !harvey_poly) {
         if (tid < nh) {
             s_lt[tid] = log(1e-3 * nz[3 * tid + 1]);
-            if (DELTA) s_lto[tid] = log(1e-3 * nzo[3 * tid + 1]);
+            if (dsub) s_lto[tid] = log(1e-3 * nzo[3 * tid + 1]);
         }
     }
     if (FARFIELD) {
@@ -309,7 +316,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
             double f[NH];
 #pragma unroll
             for (int k = 0; k < NH; k++) f[k] = 0.0;
-            const bool lane_new = (hl >= 0 && hl < nh), lane_old = DELTA && (hl >= 32 && hl < 32 + nh);
+            const bool lane_new = (hl >= 0 && hl < nh), lane_old = dsub && (hl >= 32 && hl < 32 + nh);
             if (lane_new || lane_old) {
                 const double *nq = lane_new ? nz : nzo;
                 const int ht = lane_new ? hl : hl - 32;
@@ -322,9 +329,9 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
                     double v = f[k];
                     double tot = 0.0;
                     for (int t = 0; t < nh; t++) tot = tot + __shfl(v, t, 64);
-                    if (DELTA)
+                    if (dsub)
                         for (int t = 0; t < nh; t++) tot = tot + __shfl(v, 32 + t, 64);
-                    const double wn = DELTA ? (nz[nn - 1] - nzo[nn - 1]) : nz[nn - 1];
+                    const double wn = dsub ? (nz[nn - 1] - nzo[nn - 1]) : nz[nn - 1];
                     if (hl == 0) s_coef[k] = tot + (k == 0 ? wn : 0.0);
                 }
             }
@@ -557,7 +564,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
                         const double t = exp(nz[3 * hh + 2] * (s_lt[hh] + lx));
                         Mv = fma(nz[3 * hh], rcp_nr2(t + 1.0), Mv);
                     }
-                    if (DELTA) {
+                    if (dsub) {
                         const double tauo = nzo[3 * hh + 1];
                         if (tauo != 0.0) {
                             const double t = exp(nzo[3 * hh + 2] * (s_lto[hh] + lx));
@@ -565,7 +572,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
                         }
                     }
                 }
-                Mv = Mv + (DELTA ? (white - nzo[nn - 1]) : white);
+                Mv = Mv + (dsub ? (white - nzo[nn - 1]) : white);
             }
             if (DELTA) {
                 // Mv = dM; u = dM / M0.  Change of the bin's likelihood term y/M + ln M:
@@ -575,7 +582,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
                 // reciprocals and a log1p; a bin beyond that (a step of percent size) takes the closed form -- wave-uniform choice.
                 const size_t o = (size_t)a.d_row[b] * a.Nx + (size_t)min(bin[k], a.Nx - 1);
                 const double r0 = a.model0[o], yr = a.model0[a.fd_plane + o];
-                const double u = Mv * r0;
+                const double u = (fullnew ? Mv - a.model0[2 * a.fd_plane + o] : Mv) * r0;
                 double f;
                 if (!__any(valid && !(fabs(u) <= 0.01))) {
                     double pz = fma(u, 0.2 - yr, yr - 0.25);
@@ -600,6 +607,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
                     const double r0 = FAST ? rcp_nr2(Mv) : 1.0 / Mv;
                     a.fd_rows[(size_t)b * a.Nx + bin[k]] = r0;
                     a.fd_rows[a.fd_plane + (size_t)b * a.Nx + bin[k]] = yv[k] * r0;
+                    a.fd_rows[2 * a.fd_plane + (size_t)b * a.Nx + bin[k]] = Mv;  // (for the "full table" evaluations of the DELTA launch)
                 } else a.model[(size_t)b * a.Nx + bin[k]] = Mv;
             }
         }

@@ -289,6 +289,45 @@ def test_windowed_fd_matches_full_fd(pkg, oracle, synth, ctxs):
     assert okc.mean() >= 0.95
 
 
+def test_full_table_fd_evaluations(pkg, oracle, synth, ctxs):
+    """A perturbation that moves most multiplets (splitting coefficients, the asymmetry) is evaluated by the delta launch as the WHOLE
+    perturbed table minus the stored base model row (d_flags bit 1, loglike_tile.h) instead of +new / -old row pairs.  Every splitting
+    coefficient and the asymmetry as variables, beside parameters that take the pair tables: against the brute-force batch (every
+    perturbed model rebuilt on all bins) and the oracle's forward differences."""
+    star = synth.make_c3_star(nx=40000, step=0.05)
+    o = star.plength[0] + star.plength[1] + star.plength[2:6].sum()
+    star.params[o + 13] = 12.0   # asymmetry on
+    star.params[o + 1] = 0.02    # a1 slope, so that its neighbours are not at zero either
+    y = _spectrum(oracle, star)
+    idx = np.concatenate([np.arange(o, o + 12), [o + 13], star.index_to_relax[[0, 15, 30, 60, 92]]]).astype(np.int32)
+    h = 1e-6 * np.maximum(np.abs(star.params[idx]), 1e-2)
+    T = np.array([1.0, 1.6])
+    P = np.tile(star.params, (2, 1))
+    P[1, star.index_to_relax] *= 1 + 0.002 * np.random.default_rng(8).standard_normal(star.nvars)
+    c = ctxs["fast"]
+    c.set_option(pkg.OPT_WORKGROUP, 64)
+    c.set_option(pkg.OPT_BINS_PER_THREAD, 8)
+    c.set_spectrum(star.x, y)
+    c.set_option(pkg.OPT_FD_WINDOWED, 0)
+    l0_f, g_f = c.fd_gradient(star.model_id, P, star.plength, idx, h, T, 1.0)
+    c.set_option(pkg.OPT_FD_WINDOWED, 1)
+    c.set_option(pkg.OPT_TIMING, 1)
+    c.reset_kernel_stats()
+    l0_w, g_w = c.fd_gradient(star.model_id, P, star.plength, idx, h, T, 1.0)
+    n_full = c.fd_full_tables()
+    c.set_option(pkg.OPT_TIMING, 0)
+    # a1 and a2 (constant and slope) move every l >= 1 multiplet, the asymmetry every multiplet: five full tables per vector;
+    # a3, a4 (l >= 2) and a5, a6 (l = 3) change half the rows or fewer and keep their pair tables, like the single-mode parameters
+    assert n_full == 5 * P.shape[0], n_full
+    assert np.allclose(l0_w, l0_f, rtol=1e-12)
+    scale = np.max(np.abs(g_f), axis=1, keepdims=True)
+    tol = 5e-15 * star.x.size / h[None, :] + 1e-6 * scale
+    assert np.all(np.abs(g_w - g_f) <= tol), np.max(np.abs(g_w - g_f) / tol)
+    assert np.all(np.abs(g_w[:, :13]) > 0)   # every splitting coefficient and the asymmetry move the likelihood
+    _, l0_o, g_o = oracle.fd_gradient(star.model_id, star.params, star.plength, idx, h, star.x, y, 1.0, 1.0)
+    assert np.all(np.abs(g_w[0] - g_o) <= 5e-14 * star.x.size / h + 1e-6 * np.max(np.abs(g_o)))
+
+
 def test_many_multiplets_multiple_chunks(pkg, oracle, synth, ctxs):
     """More than 64 multiplets per evaluation (the kernel stages them in chunks of 64): 30 radial orders x l<=3 = 120
     multiplets (BASELINE config C5 has O(100-300)); every mode and geometry family, plus the windowed gradient."""
