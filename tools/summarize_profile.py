@@ -56,7 +56,7 @@ if calib:
               "correction of MI355X_MICROARCH.md applies unchanged.", ""]
 if agg:
     mean = {k: sum(v) / len(v) for k, v in agg.items()}
-    lines += [f"## PMC, kernel `{KERNEL}` (fused step: 20 evaluations x 196 tiles + candidate roles + settle), mean over {len(next(iter(agg.values())))} launches of "
+    lines += [f"## PMC, kernel `{KERNEL}` (fused step: one chain group's likelihood tiles, each deciding the previous iteration for its chain first, + commit workgroups + candidate roles + L z blocks), mean over {len(next(iter(agg.values())))} launches of "
               "`bench.py --headline-only --steps 300`, separate passes", "", "| counter | mean per launch |", "|---|---|"]
     for k in sorted(mean):
         lines.append(f"| {k} | {mean[k]:.4g} |")
