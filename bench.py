@@ -167,14 +167,14 @@ def main():
     ctx.set_spectrum(star.x, y)
     T = lam ** np.arange(a.chains)
 
-    def make_sampler(use_drift, engine):
-        return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=engine, Nt_learn=SETUP_LEARN,
+    def make_sampler(use_drift, engine, learn=SETUP_LEARN):
+        return pkg.Sampler(ctx, star, nchains=a.chains, lambda_temp=lam, use_drift=use_drift, seed=7 + rank, engine=engine, Nt_learn=learn,
                            periods_learn=(1,), dN_mixing=a.dn_mixing, c0=2.0)
 
     from tamcmc_c_amd import shard
     mark("imports, library load, synthetic star, spectrum upload")
     use_drift = 1 if a.sampler == "mala" else 0
-    smp = make_sampler(use_drift, a.engine)
+    smp = make_sampler(use_drift, a.engine, learn=(100, 300) if use_drift else SETUP_LEARN)  # (mala: its set-up phase is 300 iterations)
     # record buffers the run() calls fill: the samples and the statistics of every iteration (page-locked, like a writer's ring buffer;
     # the device engine writes the records straight into them)
     nrec = max(a.steps, a.warmup, 1)
@@ -216,8 +216,11 @@ def main():
 
     extra = {}
     if a.mala_steps > 0 and a.sampler == "mh" and world == 1:
-        ms = make_sampler(1, a.engine)
-        ms.run(300, record=False)   # adaptation in [100, 300): the Langevin proposal needs its step size tuned
+        # adaptation in [100, 300), as the 300 set-up iterations below: the Langevin proposal needs its step size tuned; the timed steps are
+        # acquire-phase steps like the headline's (rounds 1-2 left the learning window open -- (100, 1100) -- so every timed step also
+        # paid a covariance update and a Cholesky factor, ~45 us of the step)
+        ms = make_sampler(1, a.engine, learn=(100, 300))
+        ms.run(300, record=False)
         ctx.reset_kernel_stats()
         torch.cuda.synchronize()
         t1 = time.perf_counter()

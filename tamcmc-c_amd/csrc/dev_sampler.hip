@@ -2255,7 +2255,7 @@ int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *sampl
             DCHK(hipStreamSynchronize(st));
             DCHK(I.fd_part.reserve(nb.nS * (size_t)nb.ntiles * 2));
             DCHK(I.fd_S.reserve(nb.nS));
-            if (nb.windowed) DCHK(I.fd_model.reserve(3 * C * (size_t)c->Nx));  // three planes: 1/M0, y/M0, M0 of the base points
+            if (nb.windowed) DCHK(I.fd_model.reserve(3 * C * (size_t)c->Nx + 2 * C * (size_t)nb.ntiles * FD_MOM + ((size_t)nb.B * nb.ntiles + 7) / 8));  // three planes (1/M0, y/M0, M0 of the base points) + tile moments (two layouts) + done flags
             if (c->precision == TAMCMC_PRECISION_FAST) DCHK(I.fd_bg.reserve((size_t)(nb.windowed ? a.C : nb.B) * nb.ntiles * 8));
             I.grad_valid = false;
         }
@@ -2325,7 +2325,7 @@ int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *sampl
                 DCHK(hipMemcpy(rg.data(), db + fd.o_drange, rg.size() * sizeof(int), hipMemcpyDeviceToHost));
                 long bins = 0;
                 for (int q2 = 0; q2 < fd.B; q2++) bins += rg[2 * (size_t)q2 + 1] - rg[2 * (size_t)q2];
-                fd_bins_sampled += bins;
+                fd_bins_sampled += bins - fd.bins_not_walked();
             }
         }
     }

@@ -21,6 +21,11 @@ struct FdBatch {
     int layout(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, int64_t Nparams, const int32_t *plength, int Nvars);
     int enqueue(tamcmc_hip_ctx *c, unsigned char *block, const double *d_params, double *part, double *S, double *model, double *bgbuf,
                 hipEvent_t ev0, hipEvent_t ev1);
+    // [B x ntiles] flags of the last enqueue (device memory, inside `model`): 1 = that (evaluation, tile) was a far-only tile taken from
+    // the base point's moments -- no bin of it was read; nullptr: no such pass (roofline bookkeeping: bins_not_walked)
+    const unsigned char *d_done = nullptr;
+    int tile_bins_ = 0;
+    long bins_not_walked() const;  // (synchronous copy; call after the batch has finished)
 };
 int fd_ensure_poly(tamcmc_hip_ctx *c);  // Pslm/Qlm tables in c->d_poly
 

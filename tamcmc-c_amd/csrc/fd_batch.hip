@@ -65,19 +65,11 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
         if (tid == 0) { s_base_status = *U.status; *U.status = TAMCMC_OK; *U.reject = 0; }
         __syncthreads();
     }
-    double lp_minus = 0.0;
     const bool with_prior = a.desc.prior_class != 0;
+    const int ip = e > 0 ? a.idx[e - 1] : 0;
+    const double x0 = e > 0 ? a.params[(size_t)c * Np + ip] : 0.0, hh = e > 0 ? a.h[e - 1] : 0.0;
     if (e > 0) {
-        const int i = a.idx[e - 1];
-        const double x0 = a.params[(size_t)c * Np + i], hh = a.h[e - 1];
-        if (with_prior) {
-            if (tid == 0) s_params[i] = x0 - hh;
-            __syncthreads();
-            lp_minus = wg_log_prior(a.desc, s_params, U, false);
-            if (tid == 0) *U.reject = 0;
-            __syncthreads();
-        }
-        if (tid == 0) s_params[i] = x0 + hh;
+        if (tid == 0) s_params[ip] = x0 + hh;
         __syncthreads();
     }
     double lp = 0.0;
@@ -92,9 +84,18 @@ __global__ void __launch_bounds__(FB) k_fd_unpack(const FdArgs a) {
     wg_unpack(a.desc, s_params, U, slot, a.T, true);
     if (tid == 0) {
         a.logPr_plus[slot] = lp;
-        a.logPr_minus[slot] = lp_minus;
         a.status[slot] = *U.status;
     }
+    // the log-prior at theta - h e_k is only ever looked at when the forward point lies outside a prior's support (one-sided fallback of
+    // the gradient's prior share): evaluated in that case alone (workgroup-uniform: every lane holds the same lp)
+    double lp_minus = 0.0;
+    if (e > 0 && with_prior && !isfinite(lp)) {
+        __syncthreads();
+        if (tid == 0) { s_params[ip] = x0 - hh; *U.reject = 0; }
+        __syncthreads();
+        lp_minus = wg_log_prior(a.desc, s_params, U, false);
+    }
+    if (tid == 0) a.logPr_minus[slot] = lp_minus;
     if (!a.windowed) return;
     __syncthreads();
     const int stride = a.desc.stride;
@@ -243,7 +244,7 @@ int FdBatch::layout(tamcmc_hip_ctx *c, int model_id_, int prior_class_, int C_, 
 }
 
 // db = the batch's device block (total_bytes), constants in place; d_params: C x Np parameter vectors on the device (nullptr: the
-// block's own params area); part / S / model: scratch sized nS*ntiles*2, nS, C*Nx (model only when windowed); bgbuf: C or B x ntiles x 8.
+// block's own params area); part / S / model: scratch sized nS*ntiles*2, nS, 3*C*Nx + 2*C*ntiles*FD_MOM + ceil(B*ntiles/8) (model only when windowed); bgbuf: C or B x ntiles x 8.
 int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_params, double *part, double *S, double *model, double *bgbuf,
                      hipEvent_t ev0, hipEvent_t ev1) {
     hipStream_t st = c->stream;
@@ -307,18 +308,40 @@ int FdBatch::enqueue(tamcmc_hip_ctx *c, unsigned char *db, const double *d_param
         }
         HIPCHK(c, launch_loglike(a, c->precision, c->wgs, c->K, true, st));
         HIPCHK(c, launch_finalize(part, C, ntiles, S, st));
+        // (1b) moments of the base points per tile, behind the three planes: the delta launch's far-only tiles take their sums from them
+        double *mom = (c->precision == TAMCMC_PRECISION_FAST && c->wgs == 64) ? model + 3 * (size_t)C * Nx : nullptr;
+        double *momT = mom ? mom + (size_t)C * ntiles * FD_MOM : nullptr;
+        if (mom) HIPCHK(c, launch_fd_moments(a, c->wgs, c->K, mom, momT, st));
         // (2) the C*Nvars perturbed points: log-likelihood DIFFERENCES from the delta tables
         LoglikeArgs d = a;
+        d.fd_mom = mom;
+        d.fd_momT = momT;
         d.B = B; d.model = nullptr; d.fd_rows = nullptr;
         d.bg_poly = fa.full_tables ? bgbuf : nullptr;  // (rows by base point: read by the "full table" evaluations only)
         d.mults = fa.D.mults; d.offsets = fa.D.pairs; d.noise = fa.D.noise; d.nharvey = fa.D.nh; d.nnoise = fa.D.nn;
         d.partials = part + (size_t)C * ntiles * 2;
         d.d_range = fa.d_range; d.d_flags = fa.d_flags; d.d_row = fa.d_row; d.d_noise_old = fa.d_noise_old; d.model0 = model;
+        if (mom) {  // (2a) the far-only tiles of the light evaluations, one lane per tile; the delta launch skips what this marks done
+            unsigned char *done = (unsigned char *)(momT + (size_t)C * ntiles * FD_MOM);
+            HIPCHK(c, launch_fd_far(d, c->wgs, c->K, done, st));
+            d.d_done = done;
+        }
+        d_done = d.d_done;
+        tile_bins_ = tile_bins(c->wgs, c->K);
         HIPCHK(c, launch_loglike_delta(d, c->precision, c->wgs, c->K, st));
         HIPCHK(c, launch_finalize(d.partials, B, ntiles, S + C, st));
     }
     if (ev1) HIPCHK(c, hipEventRecord(ev1, st));
     return TAMCMC_OK;
+}
+
+long FdBatch::bins_not_walked() const {
+    if (!d_done) return 0;
+    std::vector<unsigned char> f((size_t)B * ntiles);
+    if (hipMemcpy(f.data(), d_done, f.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    long n = 0;
+    for (unsigned char v : f) n += v ? 1 : 0;
+    return n * (long)tile_bins_;
 }
 
 int fd_ensure_poly(tamcmc_hip_ctx *c) {
@@ -375,7 +398,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
     HIPCHK(c, c->d_part.reserve(nS * fb.ntiles * 2));
     HIPCHK(c, c->d_S.reserve(nS));
     HIPCHK(c, c->h_S.reserve(nS));
-    if (windowed) HIPCHK(c, c->d_model.reserve(3 * (size_t)C * c->Nx));  // three planes: 1/M0, y/M0, M0
+    if (windowed) HIPCHK(c, c->d_model.reserve(3 * (size_t)C * c->Nx + 2 * (size_t)C * fb.ntiles * FD_MOM + ((size_t)fb.B * fb.ntiles + 7) / 8));  // three planes: 1/M0, y/M0, M0; tile moments (two layouts); done flags
     if (c->precision == TAMCMC_PRECISION_FAST) HIPCHK(c, c->d_bg.reserve((size_t)(windowed ? C : B) * fb.ntiles * 8));
     rc = fb.enqueue(c, db, nullptr, c->d_part.p, c->d_S.p, c->d_model.p, c->d_bg.p, c->timing ? c->ev0 : nullptr, c->timing ? c->ev1 : nullptr);
     if (rc) return rc;
@@ -392,6 +415,7 @@ static int fd_run(tamcmc_hip_ctx *c, int model_id, int prior_class, int C, const
             std::vector<int> rg((size_t)2 * B);
             HIPCHK(c, hipMemcpy(rg.data(), db + o_drange, rg.size() * sizeof(int), hipMemcpyDeviceToHost));
             for (int s = 0; s < B; s++) c->fd_bins += rg[2 * (size_t)s + 1] - rg[2 * (size_t)s];
+            c->fd_bins -= fb.bins_not_walked();  // (far-only tiles taken from the base point's moments)
             c->fd_delta_evals += B;
             std::vector<int> fl((size_t)B);
             HIPCHK(c, hipMemcpy(fl.data(), db + fb.o_dflags, fl.size() * sizeof(int), hipMemcpyDeviceToHost));

@@ -48,7 +48,14 @@ struct LoglikeArgs {
     const double *model0 = nullptr;
     double *fd_rows = nullptr;
     size_t fd_plane = 0;
+    // DELTA, tiles whose changed multiplets are all in the far field: moments of the base point per (row, tile), FD_MOM doubles each
+    // (launch_fd_moments), or nullptr: every such tile walks its bins
+    const double *fd_mom = nullptr;
+    const double *fd_momT = nullptr;  // the same moments as [rows x FD_MOM x ntiles] (launch_fd_far: one lane per tile reads along the tiles)
+    // DELTA: [B x ntiles] 1 = this (evaluation, tile) is already done (launch_fd_far wrote its partial sums): the workgroup leaves at once
+    const unsigned char *d_done = nullptr;
 };
+constexpr int FD_MOM = 48;  // 16 first-order + 31 second-order moments + max 1/M0 (loglike_tile.h, DELTA far-only tiles)
 
 // Tile to dispatch first: three tiles below the lowest multiplet centre of a representative table (so the near-field tiles lead
 // the launch).  A hint only -- results do not depend on it.
@@ -73,5 +80,12 @@ hipError_t launch_loglike_delta(LoglikeArgs a, int mode, int wgs, int K, hipStre
 // fills bg[B x ntiles x 8] for launch_loglike(a with a.bg_poly = bg, FAST mode, same wgs/K): one thread per (evaluation, tile)
 hipError_t launch_bg_poly(const LoglikeArgs &a, int wgs, int K, double *bg, hipStream_t st);
 hipError_t launch_finalize(const double *partials, int B, int ntiles, double *S, hipStream_t st);
+// moments of the base points of a finite-difference batch for the DELTA launch's far-only tiles: a.fd_rows (the planes the base launch
+// left), a.B rows, geometry (wgs, K) of the DELTA launch -> mom[B x ntiles x FD_MOM] and its transpose momT[B x FD_MOM x ntiles]
+hipError_t launch_fd_moments(const LoglikeArgs &a, int wgs, int K, double *mom, double *momT, hipStream_t st);
+// DELTA launch arguments `d` (delta tables, a.fd_mom set): every (evaluation, tile) whose changed multiplets are ALL in the tile's far
+// field is evaluated here, one lane per tile -- its partial sums written, done[b x ntiles] set to 1 -- for the evaluations with few
+// rows (a perturbed frequency, width or height: most tiles of their windows); everything else gets done = 0 and is the DELTA launch's.
+hipError_t launch_fd_far(const LoglikeArgs &d, int wgs, int K, unsigned char *done, hipStream_t st);
 
 }  // namespace tamcmc

@@ -255,6 +255,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
     const int t0 = tile * TILE;
     const int t1 = min(t0 + TILE, a.Nx);
     if (DELTA) {  // tiles outside the affected bin range contribute exactly 0 (workgroup-uniform exit before any barrier)
+        if (a.d_done && a.d_done[(size_t)b * a.ntiles + tile]) return;  // a far-only tile of a light evaluation: k_fd_far (kernels.hip) did it
         const int lo = a.d_range[2 * b], hi = a.d_range[2 * b + 1];
         if (t1 <= lo || t0 >= hi) {
             if (tid == 0) {
@@ -340,6 +341,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
 
     // the table builder already summed the series of this (evaluation, tile) (bg_series.h, same arithmetic): still in registers
     bool bg_in_regs = harvey_poly && bg_prebuilt;
+    bool any_near = false;  // (workgroup-uniform) a chunk held a multiplet of the near field
     KSTAMP(1);
     for (int c0 = mbeg; c0 < mend; c0 += CHUNK) {
         __syncthreads();  // previous chunk fully consumed
@@ -429,6 +431,7 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
         __syncthreads();
         KSTAMP(2);
         const int n = PROBE_SKIP(1) ? 0 : s_n;
+        any_near = any_near || (s_n > 0);
         for (int q = 0; q < n; q++) {
             const LdsMult &M = s_m[q];  // (near multiplets only: the staging pass put them first)
             switch (M.l) {  // wave-uniform
@@ -514,6 +517,37 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
 #pragma unroll
     for (int k = 0; k < K; k++) yv[k] = DELTA ? 0.0 : a.y[min(bin[k], a.Nx - 1)];  // (DELTA: y enters through the base point's y/M0 plane)
     if (FAST) __syncthreads();  // s_lt / s_coef visible (also when the evaluation has no multiplet chunk)
+    if constexpr (DELTA && FARFIELD && WGS == 64) {
+        // A tile whose changed multiplets are ALL in its far field (most tiles of a perturbed frequency's window: the mode is near for
+        // three or four of a hundred) has dM = P(s), the tile polynomial, with |u| = |dM / M0| ~ 1e-7 of a far wing: the change of its
+        // likelihood terms, sum_b [(1 - y/M0) u - (1/2 - y/M0) u^2], is a dot product of the polynomial's coefficients (and of their
+        // self-convolution) with moments of the base point on this tile (k_fd_moments, kernels.hip) -- no bin is walked.  Omitted:
+        // u^3, below 1e-10 of the leading term when max|u| <= 1e-5 (bounded by sum|c_k| max(1/M0)); a tile beyond that walks its bins.
+        if (a.fd_mom && !bg && !fullnew && !any_near) {  // workgroup-uniform
+            const double *mm = a.fd_mom + ((size_t)a.d_row[b] * a.ntiles + tile) * FD_MOM;
+            const double w1 = (tid < NC) ? mm[tid] : 0.0, w2 = (tid < 2 * NC - 1) ? mm[NC + tid] : 0.0, rmax = mm[FD_MOM - 1];
+            const double ck = (tid < NC) ? s_coef[tid] : 0.0;
+            double ab = fabs(ck);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) ab = ab + __shfl_xor(ab, off, 64);
+            if (ab * rmax <= 1e-5) {  // (false for NaN)
+                double cv = 0.0;  // (c * c)_tid
+                if (tid < 2 * NC - 1) {
+                    const int j0 = tid < NC ? 0 : tid - (NC - 1), j1 = tid < NC ? tid : NC - 1;
+                    for (int j = j0; j <= j1; j++) cv = fma(s_coef[j], s_coef[tid - j], cv);
+                }
+                double tot = fma(ck, w1, cv * w2);
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tot = tot + __shfl_xor(tot, off, 64);
+                if (tid == 0) {
+                    double *p = a.partials + ((size_t)b * a.ntiles + tile) * 2;
+                    p[0] = tot;
+                    p[1] = 0.0;
+                }
+                return;
+            }
+        }
+    }
     if (FARFIELD) {
         if (s_anyfar && !PROBE_SKIP(4)) {  // workgroup-uniform: far multiplets and/or the background series
             const double inv_h = 1.0 / h;

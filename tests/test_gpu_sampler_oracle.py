@@ -246,7 +246,8 @@ def test_langevin_iteration_equals_the_oracle_on_a_local_slice(pkg, oracle, synt
     ctx = pkg.HipContext(0, precision=pkg.PRECISION_FAST)
     ctx.set_spectrum(star.x, y)
     _langevin_walk(pkg, oracle, star, y, ctx, 10, 1.7, engine, 5, 1e-7, delta, adapt_to=150, n_settle=20,
-                   want_swaps=((2, (0.0, 0.05)), (4, (0.0, 0.05)), (4, (0.97, 1.0)), (7, (0.97, 1.0))))
+                   want_swaps=((2, (0.0, 0.05)), (4, (0.0, 0.05)), (4, (0.97, 1.0)), (7, (0.97, 1.0)), (1, (0.97, 1.0)), (8, (0.97, 1.0)),
+                               (5, (0.985, 1.0))))   # (several pairs asked to refuse: a pair whose swap probability is 1 swaps whatever u)
     ctx.close()
 
 

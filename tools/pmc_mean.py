@@ -7,6 +7,6 @@ agg = collections.defaultdict(list)
 for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"]:
-            agg[(r["Kernel_Name"].split("(")[0][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(agg.items()):
     print(f"{k:60s} {c:24s} n={len(v):6d} mean={sum(v) / len(v):14.1f}")
