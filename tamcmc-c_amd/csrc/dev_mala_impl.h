@@ -126,17 +126,48 @@ __global__ void __launch_bounds__(TB) k_mala_test(const DevSamplerArgs a, const 
     // both triangular solves in one sweep, column by column: row i receives its subtractions in ascending k, like the row-wise
     // substitution of multinormal_logpdf (host_mala.cpp)
     const double *LT = a.LT + (size_t)m * Nv * Nv;  // LT[k*Nv + i] = L[i][k]
-    for (int k = 0; k < Nv; k++) {
-        if (tid == 0) { const double d = LT[(size_t)k * Nv + k]; sf[k] = sf[k] / d; sr[k] = sr[k] / d; }
+    if (a.chol_in_lds && Nv <= 128) {
+        // The factor in LDS (the adaptation's work area: the launch always reserves it when it fits), the two right-hand sides in the
+        // registers of ONE wave (lane i: rows i and i + 64), the solved component of a column handed on by a lane read: no barrier and no
+        // memory round trip per column (93 columns x two barriers x an L2 read were 45 us of this kernel), and the pivots' reciprocals
+        // taken once beforehand, all at a time (a product with 1/d instead of a division by d in the chain: 1 ulp).
+        double *Ls = s_A, *inv_d = s_A + (size_t)Nv * Nv;
+        for (int i = tid; i < Nv * Nv; i += TB) Ls[i] = LT[i];
+        for (int k = tid; k < Nv; k += TB) inv_d[k] = 1.0 / LT[(size_t)k * Nv + k];
         __syncthreads();
-        const double wf = sf[k], wr = sr[k];
-        for (int i = k + 1 + tid; i < Nv; i += TB) {
-            const double l = LT[(size_t)k * Nv + i];
-            sf[i] = sf[i] - l * wf;
-            sr[i] = sr[i] - l * wr;
+        if (tid < 64) {
+            const int lane = tid, hi = lane + 64;
+            double f0 = lane < Nv ? sf[lane] : 0.0, f1 = hi < Nv ? sf[hi] : 0.0, r0 = lane < Nv ? sr[lane] : 0.0, r1 = hi < Nv ? sr[hi] : 0.0;
+#pragma clang loop unroll(disable)
+            for (int k = 0; k < Nv; k++) {
+                const double *row = Ls + (size_t)k * Nv;
+                const double id = inv_d[k];
+                const double l0 = (lane > k && lane < Nv) ? row[lane] : 0.0, l1 = (hi > k && hi < Nv) ? row[hi] : 0.0;
+                const double wf = (k < 64 ? __shfl(f0, k, 64) : __shfl(f1, k - 64, 64)) * id;
+                const double wr = (k < 64 ? __shfl(r0, k, 64) : __shfl(r1, k - 64, 64)) * id;
+                if (lane == (k & 63)) {
+                    if (k < 64) { f0 = wf; r0 = wr; }
+                    else { f1 = wf; r1 = wr; }
+                }
+                f0 = f0 - l0 * wf; r0 = r0 - l0 * wr;  // (rows above the column: l = 0, the value stays)
+                f1 = f1 - l1 * wf; r1 = r1 - l1 * wr;
+            }
+            if (lane < Nv) { sf[lane] = f0; sr[lane] = r0; }
+            if (hi < Nv) { sf[hi] = f1; sr[hi] = r1; }
         }
         __syncthreads();
-    }
+    } else
+        for (int k = 0; k < Nv; k++) {
+            if (tid == 0) { const double d = LT[(size_t)k * Nv + k]; sf[k] = sf[k] / d; sr[k] = sr[k] / d; }
+            __syncthreads();
+            const double wf = sf[k], wr = sr[k];
+            for (int i = k + 1 + tid; i < Nv; i += TB) {
+                const double l = LT[(size_t)k * Nv + i];
+                sf[i] = sf[i] - l * wf;
+                sr[i] = sr[i] - l * wr;
+            }
+            __syncthreads();
+        }
     double qf = 0, qr = 0;
     for (int i = tid; i < Nv; i += TB) { qf += sf[i] * sf[i]; qr += sr[i] * sr[i]; }
     qf = wg_sum(qf, s_red);

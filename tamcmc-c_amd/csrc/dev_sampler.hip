@@ -2312,7 +2312,8 @@ int DevSampler::run_mala(long it0, long n_iter, const char *learn, double *sampl
         int rc = batch(a.params_prop, timed);
         if (rc) return rc;
         const int learn_i = (learn && learn[i]) ? 1 : 0;
-        hipLaunchKernelGGL(k_mala_test, dim3(a.C), dim3(TB), lds_test0 + ((learn_i && chol_lds) ? lds_adapt : 0), st, args, M, it, P, learn_i,
+        // (the adaptation's work area is reserved in every step when it fits: without adaptation the triangular solves keep the factor there)
+        hipLaunchKernelGGL(k_mala_test, dim3(a.C), dim3(TB), lds_test0 + (chol_lds ? lds_adapt : 0), st, args, M, it, P, learn_i,
                            I.adapt_scratch);
         if (timed) {
             DCHK(hipStreamSynchronize(st));
