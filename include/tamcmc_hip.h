@@ -152,7 +152,12 @@ int tamcmc_hip_rgb_mixed_modes(tamcmc_hip_ctx *ctx, int model_id, const double *
 /* Forward-difference gradient of the tempered logL (the drift MALA::D_MALA leaves as a stub, MALA.cpp:321-328):
  * for each of the C chains, Nvars+1 evaluations in ONE batched launch.
  * params: C x Nparams; index_to_relax: Nvars parameter indices (model_def.cpp:76-90); hstep: Nvars steps.
- * Out: logL0[C], grad[C x Nvars] = (logL(theta + h e_k) - logL(theta)) / h_applied. */
+ * Out: logL0[C], grad[C x Nvars] = (logL(theta + h e_k) - logL(theta)) / h_applied.
+ * Tolerance (FAST arithmetic, windowed differences: TAMCMC_OPT_FD_WINDOWED): the difference is formed term by term against the stored
+ * base point -- per bin as the series in u = dM/M0 (five terms, closed form beyond |u| = 0.01), and on tiles where every changed
+ * multiplet is in the far field from moments of the base point (first and second order in u; used where max|u| <= 1e-5, what is
+ * omitted is below 1e-10 of the leading term).  Against the brute-force difference of two full evaluations it agrees to that
+ * difference's own cancellation noise (~5e-15 Nx / h) + 1e-6 of the gradient's scale (tests/test_gpu_parity.py). */
 int tamcmc_hip_fd_gradient(tamcmc_hip_ctx *ctx, int model_id, int C, const double *params, int64_t Nparams,
                            const int32_t *plength, const int32_t *index_to_relax, int Nvars, const double *hstep,
                            const double *Tcoefs, double p, double *logL0, double *grad);
