@@ -523,7 +523,8 @@ __device__ __forceinline__ void tile_compute(const LoglikeArgs &a, const int til
         // likelihood terms, sum_b [(1 - y/M0) u - (1/2 - y/M0) u^2], is a dot product of the polynomial's coefficients (and of their
         // self-convolution) with moments of the base point on this tile (k_fd_moments, kernels.hip) -- no bin is walked.  Omitted:
         // u^3, below 1e-10 of the leading term when max|u| <= 1e-5 (bounded by sum|c_k| max(1/M0)); a tile beyond that walks its bins.
-        if (a.fd_mom && !bg && !fullnew && !any_near) {  // workgroup-uniform
+        // (a perturbed noise parameter has no rows: its dM is the difference of two background series, a polynomial wherever the series is valid)
+        if (a.fd_mom && (!bg || harvey_poly) && !fullnew && !any_near) {  // workgroup-uniform
             const double *mm = a.fd_mom + ((size_t)a.d_row[b] * a.ntiles + tile) * FD_MOM;
             const double w1 = (tid < NC) ? mm[tid] : 0.0, w2 = (tid < 2 * NC - 1) ? mm[NC + tid] : 0.0, rmax = mm[FD_MOM - 1];
             const double ck = (tid < NC) ? s_coef[tid] : 0.0;
