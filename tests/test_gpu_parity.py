@@ -328,6 +328,40 @@ def test_full_table_fd_evaluations(pkg, oracle, synth, ctxs):
     assert np.all(np.abs(g_w[0] - g_o) <= 5e-14 * star.x.size / h + 1e-6 * np.max(np.abs(g_o)))
 
 
+def test_far_only_tiles_come_from_the_moments(pkg, oracle, synth, ctxs):
+    """A perturbed frequency moves two or three multiplets whose windows span many tiles, and is in the far field of most of them: those
+    tiles are taken from moments of the base point (k_fd_moments / k_fd_far, kernels.hip) and no bin of theirs is walked.  Frequencies,
+    widths and heights as variables: the gradient equals the brute-force batch and the oracle's differences as before, and the bins the
+    delta launch walks are a small part of the spectrum (they were the affected ranges, half of it, before the moments)."""
+    star = synth.make_c3_star(nx=40000, step=0.05)
+    y = _spectrum(oracle, star)
+    names = np.array(star.names)[star.index_to_relax]
+    idx = star.index_to_relax[np.isin(names, ["Frequency_l", "Width_l0", "Height_l0"])]
+    h = 1e-6 * np.maximum(np.abs(star.params[idx]), 1e-2)
+    T = np.array([1.0, 1.5, 2.5])
+    P = np.tile(star.params, (3, 1))
+    P[1:, star.index_to_relax] *= 1 + 0.002 * np.random.default_rng(4).standard_normal((2, star.nvars))
+    c = ctxs["fast"]
+    c.set_option(pkg.OPT_WORKGROUP, 64)
+    c.set_option(pkg.OPT_BINS_PER_THREAD, 8)
+    c.set_spectrum(star.x, y)
+    c.set_option(pkg.OPT_FD_WINDOWED, 0)
+    l0_f, g_f = c.fd_gradient(star.model_id, P, star.plength, idx, h, T, 1.0)
+    c.set_option(pkg.OPT_FD_WINDOWED, 1)
+    c.set_option(pkg.OPT_TIMING, 1)
+    c.reset_kernel_stats()
+    l0_w, g_w = c.fd_gradient(star.model_id, P, star.plength, idx, h, T, 1.0)
+    bins, evals = c.fd_stats()
+    c.set_option(pkg.OPT_TIMING, 0)
+    assert evals == 3 * (idx.size + 1) and 0 < bins < 0.2 * evals * star.x.size, (bins, evals)
+    assert np.allclose(l0_w, l0_f, rtol=1e-12)
+    scale = np.max(np.abs(g_f), axis=1, keepdims=True)
+    tol = 5e-15 * star.x.size / h[None, :] + 1e-6 * scale
+    assert np.all(np.abs(g_w - g_f) <= tol), np.max(np.abs(g_w - g_f) / tol)
+    _, l0_o, g_o = oracle.fd_gradient(star.model_id, star.params, star.plength, idx, h, star.x, y, 1.0, 1.0)
+    assert np.all(np.abs(g_w[0] - g_o) <= 5e-14 * star.x.size / h + 1e-6 * np.max(np.abs(g_o)))
+
+
 def test_many_multiplets_multiple_chunks(pkg, oracle, synth, ctxs):
     """More than 64 multiplets per evaluation (the kernel stages them in chunks of 64): 30 radial orders x l<=3 = 120
     multiplets (BASELINE config C5 has O(100-300)); every mode and geometry family, plus the windowed gradient."""
