@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(WG) k_finalize(const double *partials, int nti
 // polynomial of the changed multiplets, the change of the tile's likelihood terms sum_b [(1 - y/M0) u - (1/2 - y/M0) u^2 + O(u^3)] is
 //   sum_k c_k W1_k + sum_m (c*c)_m W2_m,   W1_k = sum_b (1 - y_b/M0_b)/M0_b s_b^k,   W2_m = sum_b (y_b/M0_b - 1/2)/M0_b^2 s_b^m
 // (k < 16, m < 31; s = (x - x_c)/h on the nominal tile, as the tile polynomial is evaluated).  One wave per (tile, row); slot 47: max 1/M0.
+template <int NJ>  // bins per lane (tile_bins / 64)
 __global__ void __launch_bounds__(64) k_fd_moments(const double *x, const double *planes, size_t plane, int Nx, int ntiles, int tile_bins_, double x0,
                                                    double step, double *mom, double *momT) {
     __shared__ double s_m[64][FD_MOM + 1];
@@ -90,12 +91,20 @@ __global__ void __launch_bounds__(64) k_fd_moments(const double *x, const double
     for (int k = 0; k < NC; k++) m1[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 2 * NC - 1; k++) m2[k] = 0.0;
-#pragma clang loop unroll(disable)
-    for (int j = lane; j < tile_bins_; j += 64) {
-        const int bin = t0 + j;
-        if (bin >= Nx) break;
-        const double r0 = planes[(size_t)b * Nx + bin], yr = planes[plane + (size_t)b * Nx + bin];
-        const double sx = (x[bin] - xc) * inv_h;
+    // every bin's three values are requested before the first is used (one memory round trip per tile, not one per bin)
+    double r0v[NJ], yrv[NJ], xv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int bin = min(t0 + j * 64 + lane, Nx - 1);
+        r0v[j] = planes[(size_t)b * Nx + bin];
+        yrv[j] = planes[plane + (size_t)b * Nx + bin];
+        xv[j] = x[bin];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        if (t0 + j * 64 + lane >= Nx) continue;
+        const double r0 = r0v[j], yr = yrv[j];
+        const double sx = (xv[j] - xc) * inv_h;
         const double w1 = (1.0 - yr) * r0, w2 = (yr - 0.5) * r0 * r0;
         rmax = fmax(rmax, fabs(r0));
         double pw = 1.0;
@@ -336,7 +345,10 @@ hipError_t launch_fd_moments(const LoglikeArgs &a, int wgs, int K, double *mom, 
     const int tb = wgs * K;
     const int ntiles = (a.Nx + tb - 1) / tb;
     static_assert(FD_MOM == NC + (2 * NC - 1) + 1, "moment layout");
-    hipLaunchKernelGGL(k_fd_moments, dim3(ntiles, a.B), dim3(64), 0, st, a.x, a.fd_rows, a.fd_plane, a.Nx, ntiles, tb, a.x0, a.step, mom, momT);
+    if (tb == 256) hipLaunchKernelGGL(k_fd_moments<4>, dim3(ntiles, a.B), dim3(64), 0, st, a.x, a.fd_rows, a.fd_plane, a.Nx, ntiles, tb, a.x0, a.step, mom, momT);
+    else if (tb == 512) hipLaunchKernelGGL(k_fd_moments<8>, dim3(ntiles, a.B), dim3(64), 0, st, a.x, a.fd_rows, a.fd_plane, a.Nx, ntiles, tb, a.x0, a.step, mom, momT);
+    else if (tb == 1024) hipLaunchKernelGGL(k_fd_moments<16>, dim3(ntiles, a.B), dim3(64), 0, st, a.x, a.fd_rows, a.fd_plane, a.Nx, ntiles, tb, a.x0, a.step, mom, momT);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
