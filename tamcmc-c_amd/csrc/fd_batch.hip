@@ -5,7 +5,10 @@
 // ~20 us each, against ~4 ms of likelihood kernel); here one workgroup per (chain, perturbed variable) perturbs the
 // parameter vector, evaluates the log-prior (and the prior at the backward point, for the one-sided fallback at the
 // edge of a prior's support) and writes its multiplet table straight into the likelihood kernel's input block:
-//   k_fd_unpack (C*(Nvars+1) workgroups) -> k_loglike (one launch, B = C*(Nvars+1)) -> k_finalize.
+//   k_fd_unpack (C*(Nvars+1) workgroups) -> k_loglike (one launch, B = C*(Nvars+1)) -> k_finalize,
+// or, windowed (FAST arithmetic: the default):
+//   k_fd_unpack (tables + delta tables) -> k_loglike on the C base points (planes 1/M0, y/M0, M0 kept) -> k_fd_moments (tile moments of the
+//   base points) -> k_fd_far (far-only tiles of the light evaluations from the moments) -> k_loglike<DELTA> (everything else) -> k_finalize.
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -6,6 +6,8 @@
 //              optimum_lorentzian_calc_* :441-458,502-522, harvey_like noise_models.cpp:15-39 and
 //              likelihood_chi22p likelihoods.cpp:17-28 of the reference, for a whole batch of chains)
 // k_finalize: deterministic second-level reduction of the partials, one workgroup per evaluation.
+// k_fd_moments / k_fd_far: finite-difference batches (fd_batch.hip) -- moments of the base points per tile, and the far-only tiles of the
+//             light delta evaluations taken from them, one lane per tile (no bin walked).
 //
 // Mapping: one workgroup = 256 threads = 4 wave64 = one tile of 256*K consecutive bins of ONE evaluation.
 // x/y are read coalesced (lane i -> bin base+i); the multiplets whose window intersects the tile are
