@@ -26,6 +26,9 @@ import numpy as np
 # the 'packed' leg runs several stars' streams side by side: give every live stream its own hardware queue (ROCclr default: 4; two
 # streams that share a queue serialise).  Must be set before the HIP runtime starts; the one-star headline does not depend on it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# kernel arguments in device memory: the iteration is a chain of short dependent launches, and with the arguments fetched from host memory
+# every launch starts later (measured on this image, where 1 is already the default: 47.8 k samples/s against 40.1 k with 0)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
